@@ -1,0 +1,196 @@
+// bz_capi.hip — the extern "C" surface declared in include/bazinga_hip.h.
+#include <cstring>
+#include <string>
+
+#include "bz_solver.h"
+
+struct bz_ctx {
+    bz::Ctx c;
+};
+struct bz_problem {
+    bz_ctx* ctx;
+    bz::SolverBase* s;
+    int dtype;
+};
+
+namespace {
+thread_local std::string g_err;
+
+template <class F> int guard(F&& f) {
+    try {
+        f();
+        return BZ_OK;
+    } catch (const bz::Error& e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return BZ_ERR_ARG;
+    }
+}
+void need(const void* p, const char* what) {
+    if (!p) throw bz::Error(BZ_ERR_ARG, std::string("null argument: ") + what);
+}
+}  // namespace
+
+extern "C" {
+
+const char* bz_last_error(void) { return g_err.c_str(); }
+const char* bz_version(void) { return "bazinga-hip 0.1 (gfx950)"; }
+
+int bz_comm_unique_id(void* id128) {
+    return guard([&] {
+        need(id128, "id128");
+        static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+        ncclUniqueId id;
+        BZ_NCCL(ncclGetUniqueId(&id));
+        std::memcpy(id128, &id, sizeof(id));
+    });
+}
+
+int bz_ctx_create(const bz_ctx_opts* o, bz_ctx** out) {
+    return guard([&] {
+        need(o, "opts"); need(out, "out");
+        if (o->nranks < 1 || o->rank < 0 || o->rank >= o->nranks)
+            throw bz::Error(BZ_ERR_ARG, "rank/nranks out of range");
+        int ndev = 0;
+        BZ_HIP(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw bz::Error(BZ_ERR_HIP, "no HIP device visible");
+        if (o->device < 0 || o->device >= ndev) throw bz::Error(BZ_ERR_ARG, "device ordinal out of range");
+        auto* c = new bz_ctx();
+        try {
+            c->c.device = o->device; c->c.rank = o->rank; c->c.nranks = o->nranks;
+            BZ_HIP(hipSetDevice(o->device));
+            BZ_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
+            if (o->nranks > 1) {
+                need(o->comm_id, "comm_id");
+                ncclUniqueId id;
+                std::memcpy(&id, o->comm_id, sizeof(id));
+                BZ_NCCL(ncclCommInitRank(&c->c.comm, o->nranks, id, o->rank));
+            }
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        *out = c;
+    });
+}
+
+void bz_ctx_destroy(bz_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->c.device);
+    delete ctx;
+}
+
+int bz_device_info(bz_ctx* ctx, char* name256, int32_t* cus, int64_t* mem_bytes) {
+    return guard([&] {
+        need(ctx, "ctx");
+        hipDeviceProp_t p;
+        BZ_HIP(hipGetDeviceProperties(&p, ctx->c.device));
+        if (name256) { std::strncpy(name256, p.gcnArchName, 255); name256[255] = 0; }
+        if (cus) *cus = p.multiProcessorCount;
+        if (mem_bytes) *mem_bytes = (int64_t)p.totalGlobalMem;
+    });
+}
+
+int bz_problem_create(bz_ctx* ctx, const bz_problem_desc* d, bz_problem** out) {
+    return guard([&] {
+        need(ctx, "ctx"); need(d, "desc"); need(out, "out");
+        BZ_HIP(hipSetDevice(ctx->c.device));
+        auto* p = new bz_problem{ctx, nullptr, d->dtype};
+        try {
+            p->s = bz::make_solver(&ctx->c, *d);
+        } catch (...) {
+            delete p;
+            throw;
+        }
+        *out = p;
+    });
+}
+
+void bz_problem_destroy(bz_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->c.device);
+    delete p->s;
+    delete p;
+}
+
+void bz_panoc_default_opts(bz_panoc_opts* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->tol = 1e-8; o->maxit = 1000; o->freq = 10; o->verbose = 0;
+    o->minimum_gamma = 1e-7; o->alpha = 0.95; o->beta = 0.5;
+    o->max_backtracks = 20; o->lbfgs_memory = 5; o->fuse = 1;
+}
+
+void bz_alps_default_opts(bz_alps_opts* o, int32_t dtype) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    const double tol = dtype == BZ_F32 ? (double)1e-6f : 1e-6;   // eltype(x0)(1e-6), alps.jl:14
+    o->tol_prim = tol; o->tol_dual = tol; o->inner_tol = std::cbrt(tol);
+    o->maxit = 100; o->theta_penalty = 0.8; o->kappa_penalty = 0.5; o->kappa_tol = 0.1;
+    o->subsolver_maxit = 1000000000LL; o->verbose = 0;
+}
+
+int bz_problem_set_multipliers(bz_problem* p, const void* mu, const void* y) {
+    return guard([&] { need(p, "problem"); need(mu, "mu"); need(y, "y"); p->s->set_multipliers(mu, y); });
+}
+
+int bz_panoc_solve(bz_problem* p, const bz_panoc_opts* o, const void* x0, void* x_out,
+                   bz_panoc_stats* st) {
+    return guard([&] {
+        need(p, "problem"); need(o, "opts"); need(x0, "x0"); need(x_out, "x_out");
+        p->s->solve(*o, x0, x_out, st);
+    });
+}
+
+int bz_panoc_begin(bz_problem* p, const bz_panoc_opts* o, const void* x0) {
+    return guard([&] { need(p, "problem"); need(o, "opts"); need(x0, "x0"); p->s->begin(*o, x0); });
+}
+int bz_panoc_step(bz_problem* p) {
+    return guard([&] { need(p, "problem"); p->s->step(); });
+}
+int bz_panoc_finish(bz_problem* p, void* x_out, bz_panoc_stats* st) {
+    return guard([&] { need(p, "problem"); p->s->finish(x_out, st); });
+}
+int bz_panoc_scalars(bz_problem* p, double* out16) {
+    return guard([&] { need(p, "problem"); need(out16, "out16"); p->s->scalars(out16); });
+}
+int bz_panoc_vector(bz_problem* p, int32_t which, void* out) {
+    return guard([&] { need(p, "problem"); need(out, "out"); p->s->vector(which, out); });
+}
+
+int bz_alps_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po, const void* x0,
+                  const void* y0, void* x, void* y, void* s, void* mu, bz_alps_stats* st) {
+    return guard([&] {
+        need(p, "problem"); need(ao, "alps opts"); need(po, "panoc opts");
+        need(x0, "x0"); need(y0, "y0"); need(x, "x"); need(y, "y"); need(s, "s"); need(mu, "mu");
+        p->s->alps(*ao, *po, x0, y0, x, y, s, mu, st);
+    });
+}
+
+int bz_eval_al_gradient(bz_problem* p, const void* x, void* dlx, double* vals3) {
+    return guard([&] { need(p, "problem"); need(x, "x"); need(vals3, "vals3"); p->s->eval_al_gradient(x, dlx, vals3); });
+}
+int bz_eval_prox(bz_problem* p, const void* x, double gamma, void* z, double* gz) {
+    return guard([&] { need(p, "problem"); need(x, "x"); need(z, "z"); need(gz, "gz"); p->s->eval_prox(x, gamma, z, gz); });
+}
+int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y, const void* v, void* d) {
+    return guard([&] {
+        need(p, "problem"); need(v, "v"); need(d, "d");
+        if (m > 0) { need(S, "S"); need(Y, "Y"); }
+        p->s->eval_lbfgs(m, S, Y, v, d);
+    });
+}
+
+int bz_profile_enable(bz_problem* p, int32_t on) {
+    return guard([&] { need(p, "problem"); p->s->profile_enable(on != 0); });
+}
+int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms) {
+    return guard([&] { need(p, "problem"); need(launches, "launches"); need(total_ms, "total_ms"); p->s->profile_get(category, launches, total_ms); });
+}
+int bz_profile_reset(bz_problem* p) {
+    return guard([&] { need(p, "problem"); p->s->profile_reset(); });
+}
+
+}  // extern "C"

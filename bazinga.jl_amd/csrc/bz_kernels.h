@@ -1,0 +1,739 @@
+// bz_kernels.h — hand-written gfx950 kernels for the PANOCplus hot path.
+//
+// Every kernel here is a streaming, HBM-bound vector pass (arithmetic intensity
+// 0.1-0.2 flop/B), so the design rules are the ones for bandwidth, not MFMA:
+//   * 16 B per lane per access (double2 / float4), unit stride, 256-thread blocks,
+//     a grid of <= 2048 blocks that grid-strides the vector;
+//   * reductions: per-thread fp64 accumulators -> wave64 shuffle tree -> LDS across
+//     the 4 waves -> one partial per block.  The NEXT kernel (or the collect
+//     kernel) folds the <= 2048 partials in a fixed order, so every scalar is
+//     bit-reproducible and no atomics / fences / grid barriers are needed;
+//   * coefficients of the L-BFGS two-loop (alpha_i, beta_i) never visit the host:
+//     each axpy+dot kernel derives its coefficient from the previous kernel's
+//     partials and leaves alpha_i in a small device bank.
+//
+// Per-element arithmetic mirrors the CPU oracle operation for operation (build with
+// -ffp-contract=off), so element-wise outputs are bit-identical to oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/bazinga_hip.h"
+
+namespace bz {
+
+constexpr int BLOCK   = 256;          // 4 waves of 64
+constexpr int WAVES   = BLOCK / 64;
+constexpr int PSTRIDE = 2048;         // max grid = partials per reduction slot
+
+// where a consumer finds the pieces of a global scalar: `count` doubles `stride`
+// apart (block partials on one GPU, per-rank packs after an all-gather).
+struct ScalarSrc {
+    const double* p;
+    int count;
+    int stride;
+};
+
+template <class T> struct PackN;
+template <> struct PackN<double> { static constexpr int N = 2; };
+template <> struct PackN<float>  { static constexpr int N = 4; };
+
+template <class T> struct alignas(16) Pack {
+    T v[PackN<T>::N];
+};
+
+// problem data every element-wise kernel may need (device pointers)
+template <class T> struct ElemParams {
+    int f_kind, g_kind, D_kind, pad;
+    const T* q;
+    const T* b;
+    const T* mu;
+    const T* muy;
+    T g_lambda;
+    const T* g_u;
+    T g_lo, g_hi;
+    const T* g_lo_vec;
+    const T* g_hi_vec;
+    T D_lo, D_hi;
+    const T* D_lo_vec;
+    const T* D_hi_vec;
+};
+
+// ---------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;   // lane 0 holds the sum
+}
+__device__ __forceinline__ double nanmax(double a, double b) {
+    return (a > b || a != a) ? a : b;   // NaN-propagating max
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// fold a ScalarSrc; every thread of every block gets the same bits.
+// is_max: fold with max instead of sum.
+__device__ __forceinline__ double fold_src(ScalarSrc s, bool is_max, double* sh /*WAVES*/) {
+    double v = 0.0;
+    if (is_max) {
+        for (int i = threadIdx.x; i < s.count; i += BLOCK) v = nanmax(v, s.p[(size_t)i * s.stride]);
+        v = wave_max(v);
+    } else {
+        for (int i = threadIdx.x; i < s.count; i += BLOCK) v += s.p[(size_t)i * s.stride];
+        v = wave_sum(v);
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = is_max ? nanmax(nanmax(sh[0], sh[1]), nanmax(sh[2], sh[3]))
+                      : ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    __syncthreads();
+    return t;
+}
+
+// block-reduce K accumulators and write one partial per slot.
+// maxmask bit k set -> slot k is a max.
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[K], unsigned maxmask,
+                                                   double* parts, int first_slot) {
+    __shared__ double sh[WAVES][K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double v = ((maxmask >> k) & 1u) ? wave_max(acc[k]) : wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        int k = threadIdx.x;
+        double t = ((maxmask >> k) & 1u)
+                       ? nanmax(nanmax(sh[0][k], sh[1][k]), nanmax(sh[2][k], sh[3][k]))
+                       : ((sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]));
+        parts[(size_t)(first_slot + k) * PSTRIDE + blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 16-byte loads / stores with a scalar tail
+// ---------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ Pack<T> ld(const T* __restrict__ p, int64_t i0, int cnt) {
+    constexpr int N = PackN<T>::N;
+    Pack<T> r;
+    if (cnt == N) {
+        r = *reinterpret_cast<const Pack<T>*>(p + i0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) r.v[e] = (e < cnt) ? p[i0 + e] : T(1);
+    }
+    return r;
+}
+template <class T>
+__device__ __forceinline__ void st(T* __restrict__ p, int64_t i0, int cnt, const Pack<T>& r) {
+    constexpr int N = PackN<T>::N;
+    if (cnt == N) {
+        *reinterpret_cast<Pack<T>*>(p + i0) = r;
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+            if (e < cnt) p[i0 + e] = r.v[e];
+    }
+}
+template <class T> __device__ __forceinline__ Pack<T> splat(T s) {
+    Pack<T> r;
+#pragma unroll
+    for (int e = 0; e < PackN<T>::N; ++e) r.v[e] = s;
+    return r;
+}
+
+// canonical element->thread map shared by every kernel, so that a quantity summed
+// by two different kernels is summed in the same order (fused == unfused, bitwise)
+#define BZ_FOR_EACH_CHUNK(T, n)                                                         \
+    for (int64_t _c = (int64_t)blockIdx.x * BLOCK + threadIdx.x,                        \
+                 _nc = ((n) + PackN<T>::N - 1) / PackN<T>::N,                           \
+                 _st = (int64_t)gridDim.x * BLOCK;                                      \
+         _c < _nc; _c += _st)
+
+#define BZ_CHUNK_VARS(T, n)                                                             \
+    const int64_t i0 = _c * PackN<T>::N;                                                \
+    const int cnt = (i0 + PackN<T>::N <= (n)) ? PackN<T>::N : (int)((n) - i0);
+
+// ---------------------------------------------------------------------------
+// element-wise oracle arithmetic (mirrors oracle/bazinga_ref.py and oracle/c)
+// ---------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T proj_D(int kind, T t, T lo, T hi) {
+    // src/projections/{zeroSet,freeSet,indicatorSet}.jl
+    if (kind == BZ_D_ZERO) return T(0);
+    if (kind == BZ_D_FREE) return t;
+    return t < lo ? lo : (t > hi ? hi : t);   // IndBox prox: if x<lb lb elseif x>ub ub else x
+}
+
+template <class T> struct ALOut {
+    T grad, fterm, pterm;
+};
+
+// one element of gradient!(dlx, al, x)  (src/utilities/auglagfun.jl:73-86) with
+// c = Identity and an element-wise f.
+template <class T>
+__device__ __forceinline__ ALOut<T> al_elem(int f_kind, int D_kind, T x, T q, T b, T mu, T muy,
+                                            T lo, T hi) {
+    ALOut<T> o;
+    T cx = x;                       // eval!(cx, c, x)
+    T t = cx + muy;                 // yupd = cx + mu*y
+    T s = proj_D(D_kind, t, lo, hi);
+    t = t - s;                      // yupd -= s
+    o.pterm = (t * t) / mu;         // (yupd^2)/mu, summed then halved
+    T yupd = t / mu;                // yupd /= mu
+    T dfx;
+    if (f_kind == BZ_F_DIAG_QUADRATIC) {
+        T qx = q * x;
+        dfx = qx - b;
+        o.fterm = x * (T(0.5) * qx - b);
+    } else {
+        dfx = T(0);
+        o.fterm = T(0);
+    }
+    o.grad = dfx + yupd;            // dlx = dfx + jtv, jtv = yupd
+    return o;
+}
+
+// prox!(z, g, y, gamma) element; gl = gamma*lambda.  Returns z, adds to gsum.
+template <class T>
+__device__ __forceinline__ T prox_elem(int g_kind, T y, T gl, T u, T lo, T hi, T& gterm) {
+    T z;
+    switch (g_kind) {
+    case BZ_G_NORM_L1: {            // ProximalOperators.NormL1
+        z = y + (y <= -gl ? gl : (y >= gl ? -gl : -y));
+        gterm = z > T(0) ? z : -z;
+        break;
+    }
+    case BZ_G_NORM_L1_NONNEG: {     // normL1Nonneg.jl:29-42
+        if (y >= gl) { z = y - gl; gterm = z; } else { z = T(0); gterm = T(0); }
+        break;
+    }
+    case BZ_G_NORM_L1_BOX: {        // normL1Box.jl:30-39  max(0, min(x-gl, u))
+        T a = y - gl;
+        a = a < u ? a : u;          // min(x-gl, u)
+        z = a > T(0) ? a : T(0);    // max(0, .)
+        gterm = z;
+        break;
+    }
+    case BZ_G_IND_BOX: {
+        z = y < lo ? lo : (y > hi ? hi : y);
+        gterm = T(0);
+        break;
+    }
+    default: z = y; gterm = T(0);
+    }
+    return z;
+}
+
+template <class T> struct ElemLoads {
+    Pack<T> q, b, mu, muy, dlo, dhi, gu, glo, ghi;
+};
+
+template <class T>
+__device__ __forceinline__ void load_params(const ElemParams<T>& P, int64_t i0, int cnt,
+                                            ElemLoads<T>& L, bool need_f, bool need_al,
+                                            bool need_g) {
+    L.q = splat(T(0)); L.b = splat(T(0));
+    if (need_f && P.f_kind == BZ_F_DIAG_QUADRATIC) { L.q = ld(P.q, i0, cnt); L.b = ld(P.b, i0, cnt); }
+    if (need_al) {
+        L.mu = ld(P.mu, i0, cnt);
+        L.muy = ld(P.muy, i0, cnt);
+        L.dlo = P.D_lo_vec ? ld(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
+        L.dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
+    }
+    if (need_g) {
+        L.gu = (P.g_kind == BZ_G_NORM_L1_BOX) ? ld(P.g_u, i0, cnt) : splat(T(0));
+        L.glo = P.g_lo_vec ? ld(P.g_lo_vec, i0, cnt) : splat(P.g_lo);
+        L.ghi = P.g_hi_vec ? ld(P.g_hi_vec, i0, cnt) : splat(P.g_hi);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4: L-BFGS two-loop building block.
+//   o   = sgn*in (+ coef*v) ; if apply_H: o *= H ; if xadd: o = xadd + o
+//   out = o ; partial of sum(w .* o) -> parts[slot_out]
+// coef comes from the previous kernel's partials:
+//   mode 0 (loop 1): alpha = fold(src)/ys ; alphas[j] = alpha ; coef = -alpha
+//   mode 1 (loop 2): beta  = fold(src)/ys ; coef = alphas[j] - beta
+//   mode 2: no axpy term
+// ---------------------------------------------------------------------------
+template <class T> struct TailArgs {
+    const T* in;
+    const T* v;
+    T sgn;
+    int mode;
+    int j;
+    int apply_H;
+    ScalarSrc src;
+    T ys;
+    T H;
+    double* alphas;
+};
+
+template <class T>
+__device__ __forceinline__ T tail_coef(const TailArgs<T>& a, double* sh) {
+    if (a.mode == 2) return T(0);
+    double tot = fold_src(a.src, false, sh);
+    if (a.mode == 0) {
+        T al = T(tot) / a.ys;
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.alphas[a.j] = (double)al;
+        return -al;
+    }
+    T beta = T(tot) / a.ys;
+    return T(a.alphas[a.j]) - beta;
+}
+
+template <class T>
+__device__ __forceinline__ T tail_elem(const TailArgs<T>& a, T coef, T in, T v) {
+    T o = a.sgn * in;
+    if (a.mode != 2) {
+        T t = coef * v;
+        o = o + t;
+    }
+    if (a.apply_H) o = a.H * o;
+    return o;
+}
+
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_axpy_dot(TailArgs<T> a, const T* w, const T* xadd, T* out /* may alias a.in */, int64_t n,
+           double* __restrict__ parts, int slot_out) {
+    __shared__ double sh[WAVES];
+    const T coef = tail_coef(a, sh);
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pin = ld(a.in, i0, cnt);
+        Pack<T> pv = (a.mode != 2) ? ld(a.v, i0, cnt) : splat(T(0));
+        Pack<T> pw = w ? ld(w, i0, cnt) : splat(T(0));
+        Pack<T> px = xadd ? ld(xadd, i0, cnt) : splat(T(0));
+        Pack<T> po;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T o = tail_elem(a, coef, pin.v[e], pv.v[e]);
+            if (xadd) o = px.v[e] + o;
+            po.v[e] = o;
+            if (w && e < cnt) acc[0] += (double)(pw.v[e] * o);
+        }
+        st(out, i0, cnt, po);
+    }
+    if (w) block_reduce_store<1>(acc, 0u, parts, slot_out);
+}
+
+// plain dot:  sum a .* (sgn*b)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_dot(const T* __restrict__ a, const T* __restrict__ b, T sgn, int64_t n,
+      double* __restrict__ parts, int slot_out) {
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pa = ld(a, i0, cnt), pb = ld(b, i0, cnt);
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e)
+            if (e < cnt) acc[0] += (double)(pa.v[e] * (sgn * pb.v[e]));
+    }
+    block_reduce_store<1>(acc, 0u, parts, slot_out);
+}
+
+// ---------------------------------------------------------------------------
+// K1: AL gradient, element-wise kinds (c = Identity; f = Zero | DiagQuadratic)
+//   slots: +0 sum f terms, +1 sum t^2/mu
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, int64_t n,
+              double* __restrict__ parts, int slot0) {
+    double acc[2] = {0.0, 0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, true, true, false);
+        Pack<T> px = ld(x, i0, cnt), pg;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            ALOut<T> o = al_elem(P.f_kind, P.D_kind, px.v[e], L.q.v[e], L.b.v[e], L.mu.v[e],
+                                 L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+            pg.v[e] = o.grad;
+            if (e < cnt) { acc[0] += (double)o.fterm; acc[1] += (double)o.pterm; }
+        }
+        if (grad) st(grad, i0, cnt, pg);
+    }
+    block_reduce_store<2>(acc, 0u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
+// K3: forward-backward step  y = x - gamma*g ; z = prox(y) ; res = x - z
+//   slots: +0 sum g terms (multiply by lambda on the host), +1 <g,res>, +2 ||res||^2
+//   g == nullptr: pure prox of x (used for prox_{eps g}(x0), alps.jl:38)
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_fbstep(const T* __restrict__ x, const T* __restrict__ g, T gamma, ElemParams<T> P,
+         T* __restrict__ z, T* __restrict__ res, int64_t n, double* __restrict__ parts,
+         int slot0) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    const T gl = gamma * P.g_lambda;
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, false, false, true);
+        Pack<T> px = ld(x, i0, cnt);
+        Pack<T> pg = g ? ld(g, i0, cnt) : splat(T(0));
+        Pack<T> pz, pr;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T y = px.v[e];
+            if (g) { T t = gamma * pg.v[e]; y = px.v[e] - t; }
+            T gterm;
+            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            T r = px.v[e] - zz;
+            pz.v[e] = zz; pr.v[e] = r;
+            if (e < cnt) {
+                acc[0] += (double)gterm;
+                acc[1] += (double)(pg.v[e] * r);
+                acc[2] += (double)(r * r);
+            }
+        }
+        st(z, i0, cnt, pz);
+        if (res) st(res, i0, cnt, pr);
+    }
+    block_reduce_store<3>(acc, 0u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
+// K5+K7: L-BFGS pair + stopping norm
+//   s = x - x_prev ; y = res - res_prev ; slots: +0 <s,y>, +1 <y,y>,
+//   +2 max |res/gamma - gx + gz|
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_update(const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restrict__ res,
+         const T* __restrict__ res_prev, const T* __restrict__ gx, const T* __restrict__ gz,
+         T gamma, T* __restrict__ s_new, T* __restrict__ y_new, int64_t n,
+         double* __restrict__ parts, int slot0) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> px = ld(x, i0, cnt), pr = ld(res, i0, cnt);
+        Pack<T> pxp = x_prev ? ld(x_prev, i0, cnt) : px;
+        Pack<T> prp = res_prev ? ld(res_prev, i0, cnt) : pr;
+        Pack<T> pgx = ld(gx, i0, cnt), pgz = ld(gz, i0, cnt);
+        Pack<T> ps, py;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T s = px.v[e] - pxp.v[e];
+            T y = pr.v[e] - prp.v[e];
+            ps.v[e] = s; py.v[e] = y;
+            T w = pr.v[e] / gamma;
+            w = w - pgx.v[e];
+            w = w + pgz.v[e];
+            if (e < cnt) {
+                acc[0] += (double)(s * y);
+                acc[1] += (double)(y * y);
+                acc[2] = nanmax(acc[2], (double)(w < T(0) ? -w : w));
+            }
+        }
+        if (s_new) { st(s_new, i0, cnt, ps); st(y_new, i0, cnt, py); }
+    }
+    block_reduce_store<3>(acc, 4u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
+// The separable fast path: everything between the last two-loop reduction and the
+// end of the iteration in ONE pass (legal because f', c = I, proj_D and prox_g are all
+// element-wise, so x_d -> gradL(x_d) -> z -> gradL(z) -> (s, y) never leave registers).
+//   reads : d, S_newest, x, res_prev, q, b, mu, mu*y          (8 vectors)
+//   writes: x_d, z, res, s_new, y_new [, gradL(x_d), gradL(z)] (5 vectors)
+//   slots : +0 f(x_d) +1 pen(x_d) +2 gsum +3 <g,res> +4 ||res||^2
+//           +5 f(z) +6 pen(z) +7 <s,y> +8 <y,y> +9 max stop
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_prev,
+            ElemParams<T> P, T gamma, T* __restrict__ x_d, T* __restrict__ z,
+            T* __restrict__ res, T* __restrict__ s_new, T* __restrict__ y_new,
+            T* __restrict__ gx_out, T* __restrict__ gz_out, int64_t n,
+            double* __restrict__ parts, int slot0) {
+    __shared__ double sh[WAVES];
+    const T coef = tail_coef(a, sh);
+    const T gl = gamma * P.g_lambda;
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, true, true, true);
+        Pack<T> pin = ld(a.in, i0, cnt);
+        Pack<T> pv = (a.mode != 2) ? ld(a.v, i0, cnt) : splat(T(0));
+        Pack<T> px = ld(x, i0, cnt), prp = ld(res_prev, i0, cnt);
+        Pack<T> pxd, pz, pr, ps, py, pg1, pg2;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T d = tail_elem(a, coef, pin.v[e], pv.v[e]);
+            T xd = px.v[e] + d;
+            ALOut<T> o1 = al_elem(P.f_kind, P.D_kind, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+            T t = gamma * o1.grad;
+            T y = xd - t;
+            T gterm;
+            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            T r = xd - zz;
+            ALOut<T> o2 = al_elem(P.f_kind, P.D_kind, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+            T s = xd - px.v[e];
+            T yy = r - prp.v[e];
+            T w = r / gamma;
+            w = w - o1.grad;
+            w = w + o2.grad;
+            pxd.v[e] = xd; pz.v[e] = zz; pr.v[e] = r; ps.v[e] = s; py.v[e] = yy;
+            pg1.v[e] = o1.grad; pg2.v[e] = o2.grad;
+            if (e < cnt) {
+                acc[0] += (double)o1.fterm;
+                acc[1] += (double)o1.pterm;
+                acc[2] += (double)gterm;
+                acc[3] += (double)(o1.grad * r);
+                acc[4] += (double)(r * r);
+                acc[5] += (double)o2.fterm;
+                acc[6] += (double)o2.pterm;
+                acc[7] += (double)(s * yy);
+                acc[8] += (double)(yy * yy);
+                acc[9] = nanmax(acc[9], (double)(w < T(0) ? -w : w));
+            }
+        }
+        st(x_d, i0, cnt, pxd);
+        st(z, i0, cnt, pz);
+        st(res, i0, cnt, pr);
+        st(s_new, i0, cnt, ps);
+        st(y_new, i0, cnt, py);
+        if (gx_out) st(gx_out, i0, cnt, pg1);
+        if (gz_out) st(gz_out, i0, cnt, pg2);
+    }
+    block_reduce_store<10>(acc, 1u << 9, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+// K6: x = tau*x_d + (1-tau)*z_curr
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_blend(const T* __restrict__ x_d, const T* __restrict__ z_curr, T tau, T omt,
+        T* __restrict__ x, int64_t n) {
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> a = ld(x_d, i0, cnt), b = ld(z_curr, i0, cnt), o;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T p = tau * a.v[e];
+            T q = omt * b.v[e];
+            o.v[e] = p + q;
+        }
+        st(x, i0, cnt, o);
+    }
+}
+
+// out = in + c
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_add_scalar(const T* __restrict__ in, T c, T* __restrict__ out, int64_t n) {
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> a = ld(in, i0, cnt), o;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) o.v[e] = a.v[e] + c;
+        st(out, i0, cnt, o);
+    }
+}
+
+// slots: +0 sum (a-b)^2, +1 sum (c-d)^2     (lower_bound_smoothness_constant)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_diff_ss2(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+           const T* __restrict__ d, int64_t n, double* __restrict__ parts, int slot0) {
+    double acc[2] = {0.0, 0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pa = ld(a, i0, cnt), pb = ld(b, i0, cnt), pc = ld(c, i0, cnt), pd = ld(d, i0, cnt);
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e)
+            if (e < cnt) {
+                T u = pa.v[e] - pb.v[e];
+                T v = pc.v[e] - pd.v[e];
+                acc[0] += (double)(u * u);
+                acc[1] += (double)(v * v);
+            }
+    }
+    block_reduce_store<2>(acc, 0u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
+// K8: outer-loop element-wise work (alps.jl:62,72-84,97 ; auglagfun.jl:95-98 ;
+// safeguards.jl:2-18), kept on the device so ny-vectors never cross PCIe
+// ---------------------------------------------------------------------------
+// AugLagUpdate!: muy = mu.*y ; slots +0 sum muy*y, +1 max(mu<=0)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_muy(const T* __restrict__ mu, const T* __restrict__ y, T* __restrict__ muy, int64_t n,
+      double* __restrict__ parts, int slot0) {
+    double acc[2] = {0.0, 0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pm = ld(mu, i0, cnt), py = ld(y, i0, cnt), o;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T m = pm.v[e] * py.v[e];
+            o.v[e] = m;
+            if (e < cnt) {
+                acc[0] += (double)(m * py.v[e]);
+                acc[1] = nanmax(acc[1], (pm.v[e] <= T(0)) ? 1.0 : 0.0);
+            }
+        }
+        st(muy, i0, cnt, o);
+    }
+    block_reduce_store<2>(acc, 2u, parts, slot0);
+}
+
+// dual update with c = Identity (alps.jl:72-84):
+//   cx = x ; y = cx + muy ; s = proj_D(y) ; y -= s ; y /= mu ; slot +0 max |cx - s|
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_dual_update(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ y, T* __restrict__ s,
+              int64_t n, double* __restrict__ parts, int slot0) {
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, false, true, false);
+        Pack<T> pc = ld(cx, i0, cnt), py, ps;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T t = pc.v[e] + L.muy.v[e];
+            T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e]);
+            t = t - sv;
+            t = t / L.mu.v[e];
+            py.v[e] = t; ps.v[e] = sv;
+            T r = pc.v[e] - sv;
+            if (e < cnt) acc[0] = nanmax(acc[0], (double)(r < T(0) ? -r : r));
+        }
+        st(y, i0, cnt, py);
+        st(s, i0, cnt, ps);
+    }
+    block_reduce_store<1>(acc, 1u, parts, slot0);
+}
+
+// s = proj_D(cx) ; mu = clamp(0.1*max(1, 0.5 (cx-s)^2)/max(1,objx), 1e-8, 1e8)
+// (alps.jl:41-42, safeguards.jl:13-18; Float64 literals, stored back into T)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_penalty_init(const T* __restrict__ cx, ElemParams<T> P, double denom, T* __restrict__ s,
+               T* __restrict__ mu, int64_t n) {
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pc = ld(cx, i0, cnt), ps, pm;
+        Pack<T> dlo = P.D_lo_vec ? ld(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
+        Pack<T> dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T sv = proj_D(P.D_kind, pc.v[e], dlo.v[e], dhi.v[e]);
+            T d = pc.v[e] - sv;
+            double d2 = (double)(d * d);
+            double h = 0.5 * d2;
+            T m = (T)((h > 1.0 ? h : 1.0) / denom);
+            m = (T)((double)m * 0.1);
+            double mm = (double)m;
+            mm = mm < 1e8 ? mm : 1e8;
+            mm = mm > 1e-8 ? mm : 1e-8;
+            ps.v[e] = sv; pm.v[e] = (T)mm;
+        }
+        st(s, i0, cnt, ps);
+        st(mu, i0, cnt, pm);
+    }
+}
+
+// v = clamp(v, lo, hi)  (default_dual_safeguard!) ; v *= c
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_clamp_scale(T* __restrict__ v, double lo, double hi, T scale, int do_clamp, int64_t n) {
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> a = ld((const T*)v, i0, cnt), o;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T t = a.v[e];
+            if (do_clamp) {
+                double w = (double)t;
+                w = w < hi ? w : hi;      // min(y, 1e20)
+                w = w > lo ? w : lo;      // max(-1e20, .)
+                t = (T)w;
+            } else {
+                t = t * scale;
+            }
+            o.v[e] = t;
+        }
+        st(v, i0, cnt, o);
+    }
+}
+
+// slot +0: max |v|   (verbose display: ||res||_inf)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_absmax(const T* __restrict__ v, int64_t n, double* __restrict__ parts, int slot0) {
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> a = ld(v, i0, cnt);
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e)
+            if (e < cnt) acc[0] = nanmax(acc[0], (double)(a.v[e] < T(0) ? -a.v[e] : a.v[e]));
+    }
+    block_reduce_store<1>(acc, 1u, parts, slot0);
+}
+
+// f(x) alone for element-wise f (alps.jl:39): slot +0 sum f terms
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_fvalue_elem(const T* __restrict__ x, ElemParams<T> P, int64_t n, double* __restrict__ parts,
+              int slot0) {
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> px = ld(x, i0, cnt);
+        Pack<T> q = splat(T(0)), b = splat(T(0));
+        if (P.f_kind == BZ_F_DIAG_QUADRATIC) { q = ld(P.q, i0, cnt); b = ld(P.b, i0, cnt); }
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e)
+            if (e < cnt && P.f_kind == BZ_F_DIAG_QUADRATIC) {
+                T qx = q.v[e] * px.v[e];
+                acc[0] += (double)(px.v[e] * (T(0.5) * qx - b.v[e]));
+            }
+    }
+    block_reduce_store<1>(acc, 0u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
+// scalar plumbing
+// ---------------------------------------------------------------------------
+constexpr int MAX_COLLECT = 24;
+struct CollectArgs {
+    ScalarSrc src[MAX_COLLECT];
+    unsigned maxmask;
+    int n;
+};
+// one block: fold every source and write the scalars to (host-mapped) `out`
+__global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out);
+
+// multi-GPU: fold the block partials of slots [first, first+cnt) into send[first+i]
+__global__ void __launch_bounds__(BLOCK)
+k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, double* send);
+
+}  // namespace bz

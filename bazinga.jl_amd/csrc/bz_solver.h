@@ -1,0 +1,101 @@
+// bz_solver.h — host-side driver of the device-resident PANOCplus solve.
+//
+// The host keeps only scalars (gamma, tau, FBE, L-BFGS ring bookkeeping) and takes
+// the line-search / step-size decisions exactly as the reference's solver does
+// (ProximalAlgorithms.PANOCplus as called from src/algorithms/alps.jl:64-66); all
+// n-vectors live in HBM for the whole solve and only scalars cross PCIe: one
+// pinned-memory read-back per trial point.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <deque>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bz_kernels.h"
+
+namespace bz {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define BZ_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            throw ::bz::Error(BZ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define BZ_NCCL(expr)                                                                        \
+    do {                                                                                     \
+        ncclResult_t _r = (expr);                                                            \
+        if (_r != ncclSuccess)                                                               \
+            throw ::bz::Error(BZ_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
+    } while (0)
+
+struct Ctx {
+    int device = 0, rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    ~Ctx();
+};
+
+template <class T> struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) BZ_HIP(hipMalloc((void**)&p, (count + 8) * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    ~DBuf() { release(); }
+};
+
+// reduction slots (each slot = PSTRIDE block partials)
+enum Slot : int {
+    SL_LOOP1 = 0,      // +j, j < M : <s_j, d>
+    SL_LOOP2 = 16,     // +j, j < M : <y_j, d>
+    SL_TRIAL = 32,     // 10 slots of the fused kernel / trial sequence
+    SL_FXD = 32, SL_PXD = 33, SL_GSUM = 34, SL_DOT = 35, SL_SS = 36,
+    SL_FZ = 37, SL_PZ = 38, SL_YS = 39, SL_YTY = 40, SL_STOP = 41,
+    SL_AUX = 42,       // 2 slots: Lipschitz estimate / misc
+    SL_OUTER = 44,     // 2 slots: outer loop
+    SL_COUNT = 46
+};
+constexpr int MAX_MEM = 16;
+
+struct SolverBase {
+    virtual ~SolverBase() = default;
+    virtual void set_multipliers(const void* mu, const void* y) = 0;
+    virtual void begin(const bz_panoc_opts& o, const void* x0_host) = 0;
+    virtual void step() = 0;
+    virtual bool should_stop() const = 0;
+    virtual void finish(void* x_out, bz_panoc_stats* st) = 0;
+    virtual void scalars(double* out16) = 0;
+    virtual void vector(int which, void* out) = 0;
+    virtual void solve(const bz_panoc_opts& o, const void* x0, void* x_out, bz_panoc_stats* st) = 0;
+    virtual void alps(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0,
+                      const void* y0, void* x, void* y, void* s, void* mu, bz_alps_stats* st) = 0;
+    virtual void eval_al_gradient(const void* x, void* dlx, double* vals3) = 0;
+    virtual void eval_prox(const void* x, double gamma, void* z, double* gz) = 0;
+    virtual void eval_lbfgs(int m, const void* S, const void* Y, const void* v, void* d) = 0;
+    virtual void profile_enable(bool on) = 0;
+    virtual void profile_get(int cat, int64_t* launches, double* ms) = 0;
+    virtual void profile_reset() = 0;
+};
+
+SolverBase* make_solver(Ctx* ctx, const bz_problem_desc& d);
+
+}  // namespace bz

@@ -1,0 +1,721 @@
+// bz_solver.hip — device-resident PANOCplus / ALPS driver (host side) + kernel launches.
+//
+// Restates, for the lowered oracle kinds, what the reference runs at
+// src/algorithms/alps.jl:64-66: ProximalAlgorithms.PANOCplus(...)(f=alFun, g=gFun, x0=x)
+// with alFun = AugLagFun (src/utilities/auglagfun.jl) and gFun = NonsmoothCostFun
+// (src/utilities/nonsmoothcostfun.jl).  The scalar control flow below is the same
+// as oracle/bazinga_ref.py (PANOCplusIteration.init/step), which documents the
+// provenance of the restatement.
+#include "bz_solver.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace bz {
+
+Ctx::~Ctx() {
+    if (comm) (void)ncclCommDestroy(comm);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out) {
+    __shared__ double sh[WAVES];
+    for (int i = 0; i < a.n; ++i) {
+        double t = fold_src(a.src[i], (a.maxmask >> i) & 1u, sh);
+        if (threadIdx.x == 0) out[i] = t;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, double* send) {
+    __shared__ double sh[WAVES];
+    for (int i = 0; i < cnt; ++i) {
+        ScalarSrc s{parts + (size_t)(first + i) * PSTRIDE, grid, 1};
+        double t = fold_src(s, (maxmask >> i) & 1u, sh);
+        if (threadIdx.x == 0) send[first + i] = t;
+    }
+}
+
+enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
+                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7 };
+
+template <class T> class Solver final : public SolverBase {
+   public:
+    Solver(Ctx* c, const bz_problem_desc& d) : ctx(c), desc(d), n(d.n), ny(d.ny) {
+        if (n <= 0 || ny < 0) throw Error(BZ_ERR_ARG, "n must be positive");
+        if (d.c_kind == BZ_C_IDENTITY && ny != n)
+            throw Error(BZ_ERR_ARG, "c = Identity requires ny == n");
+        if (d.c_kind != BZ_C_IDENTITY)
+            throw Error(BZ_ERR_UNSUPPORTED, "constraint kind not lowered to the device");
+        if (d.f_kind != BZ_F_ZERO && d.f_kind != BZ_F_DIAG_QUADRATIC)
+            throw Error(BZ_ERR_UNSUPPORTED, "smooth-cost kind not lowered to the device");
+        if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_IND_BOX)
+            throw Error(BZ_ERR_ARG, "unknown g kind");
+        if (d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_BOX) throw Error(BZ_ERR_ARG, "unknown D kind");
+        if ((d.g_kind == BZ_G_NORM_L1 || d.g_kind == BZ_G_NORM_L1_NONNEG ||
+             d.g_kind == BZ_G_NORM_L1_BOX) && d.g_lambda < 0)
+            throw Error(BZ_ERR_ARG, "parameter lambda must be nonnegative");
+        BZ_HIP(hipSetDevice(ctx->device));
+        const int64_t nchunks = (n + PackN<T>::N - 1) / PackN<T>::N;
+        int g = (int)std::min<int64_t>(PSTRIDE, std::max<int64_t>(1, (nchunks + BLOCK - 1) / BLOCK));
+        if (const char* e = getenv("BZ_GRID")) g = std::max(1, std::min(PSTRIDE, atoi(e)));
+        grid = g;
+        const int64_t nychunks = (ny + PackN<T>::N - 1) / PackN<T>::N;
+        grid_y = (int)std::min<int64_t>(grid, std::max<int64_t>(1, (nychunks + BLOCK - 1) / BLOCK));
+        if (d.c_kind == BZ_C_IDENTITY) grid_y = grid;
+
+        std::memset(&P, 0, sizeof(P));
+        P.f_kind = d.f_kind; P.g_kind = d.g_kind; P.D_kind = d.D_kind;
+        if (d.f_kind == BZ_F_DIAG_QUADRATIC) {
+            if (!d.f_q || !d.f_b) throw Error(BZ_ERR_ARG, "DiagQuadratic needs q and b");
+            upload(q_, d.f_q, n); upload(b_, d.f_b, n);
+            P.q = q_.p; P.b = b_.p;
+        }
+        P.g_lambda = (T)d.g_lambda;
+        if (d.g_kind == BZ_G_NORM_L1_BOX) {
+            if (!d.g_u) throw Error(BZ_ERR_ARG, "NormL1Box needs u");
+            upload(gu_, d.g_u, n); P.g_u = gu_.p;
+        }
+        P.g_lo = (T)d.g_lo; P.g_hi = (T)d.g_hi;
+        if (d.g_kind == BZ_G_IND_BOX) {
+            if (d.g_lo_vec) { upload(glo_, d.g_lo_vec, n); P.g_lo_vec = glo_.p; }
+            if (d.g_hi_vec) { upload(ghi_, d.g_hi_vec, n); P.g_hi_vec = ghi_.p; }
+        }
+        P.D_lo = (T)d.D_lo; P.D_hi = (T)d.D_hi;
+        if (d.D_kind == BZ_D_BOX) {
+            if (d.D_lo_vec) { upload(dlo_, d.D_lo_vec, ny); P.D_lo_vec = dlo_.p; }
+            if (d.D_hi_vec) { upload(dhi_, d.D_hi_vec, ny); P.D_hi_vec = dhi_.p; }
+        }
+        mu_.alloc(ny); muy_.alloc(ny); ymul_.alloc(ny); sproj_.alloc(ny);
+        P.mu = mu_.p; P.muy = muy_.p;
+        for (auto& b : X_) b.alloc(n);
+        for (auto& b : RES_) b.alloc(n);
+        for (auto& b : Z_) b.alloc(n);
+        GX_.alloc(n); GZ_.alloc(n); D_.alloc(n); TMP_.alloc(n);
+        parts_.alloc((size_t)SL_COUNT * PSTRIDE);
+        BZ_HIP(hipMemsetAsync(parts_.p, 0, (size_t)SL_COUNT * PSTRIDE * sizeof(double), ctx->stream));
+        alphas_.alloc(MAX_MEM + 1);
+        send_.alloc(SL_COUNT);
+        recv_.alloc((size_t)SL_COUNT * std::max(1, ctx->nranks));
+        BZ_HIP(hipHostMalloc((void**)&host_out_, sizeof(double) * MAX_COLLECT, hipHostMallocMapped));
+        BZ_HIP(hipHostGetDevicePointer((void**)&host_out_dev_, host_out_, 0));
+        for (int s = 0; s < SL_COUNT; ++s) { grp_first[s] = s; grp_cnt[s] = 1; }
+        BZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+
+    ~Solver() override {
+        for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto& e : ev_pool) (void)hipEventDestroy(e);
+        if (host_out_) (void)hipHostFree(host_out_);
+    }
+
+    // ------------------------------------------------------------------ API
+    void set_multipliers(const void* mu, const void* y) override {
+        copy_in(mu_.p, mu, ny);
+        copy_in(ymul_.p, y, ny);
+        aug_lag_update();
+    }
+
+    void begin(const bz_panoc_opts& o, const void* x0_host) override {
+        copy_in(X_[0].p, x0_host, n);
+        begin_dev(o, X_[0].p);
+    }
+
+    void solve(const bz_panoc_opts& o, const void* x0, void* x_out, bz_panoc_stats* st) override {
+        begin(o, x0);
+        run_to_completion();
+        finish(x_out, st);
+    }
+
+    bool should_stop() const override {
+        return k_ >= opt.maxit || (double)stop_norm_ <= opt.tol;
+    }
+
+    void finish(void* x_out, bz_panoc_stats* st) override {
+        require_active();
+        if (x_out) copy_out(x_out, Z_[zc].p, n);
+        if (st) fill_stats(st);
+    }
+
+    void scalars(double* o) override {
+        require_active();
+        o[0] = (double)k_; o[1] = (double)gamma; o[2] = (double)tau; o[3] = (double)f_x;
+        o[4] = (double)g_z; o[5] = (double)dot_gr; o[6] = (double)ss_res; o[7] = stop_norm_;
+        o[8] = (double)last_ys; o[9] = (double)order.size(); o[10] = (double)H;
+        o[11] = (double)f_z_al; o[12] = (double)fraw_last; o[13] = (double)last_nbt;
+        o[14] = last_fused ? 1.0 : 0.0; o[15] = (double)fbe_last;
+    }
+
+    void vector(int which, void* out) override {
+        require_active();
+        switch (which) {
+        case 0: copy_out(out, X_[xc].p, n); break;
+        case 1: copy_out(out, Z_[zc].p, n); break;
+        case 2: copy_out(out, RES_[rc].p, n); break;
+        case 3:
+            if (!gx_valid) { algrad(X_[xc].p, GX_.p, SL_AUX); gx_valid = true; }
+            copy_out(out, GX_.p, n); break;
+        case 4:
+            if (!gz_valid) { algrad(Z_[zc].p, GZ_.p, SL_AUX); gz_valid = true; }
+            copy_out(out, GZ_.p, n); break;
+        default: throw Error(BZ_ERR_ARG, "unknown vector id");
+        }
+    }
+
+    void eval_al_gradient(const void* x, void* dlx, double* vals3) override {
+        copy_in(TMP_.p, x, n);
+        algrad(TMP_.p, D_.p, SL_AUX);
+        gather(SL_AUX, 2, 0u);
+        auto v = collect({SL_AUX, SL_AUX + 1}, 0u);
+        T half_pen = T(0.5) * T(v[1]);
+        vals3[0] = (double)al_value(v[0], v[1]);
+        vals3[1] = (double)T(v[0]);
+        vals3[2] = (double)half_pen;
+        if (dlx) copy_out(dlx, D_.p, n);
+    }
+
+    void eval_prox(const void* x, double gam, void* z, double* gz) override {
+        copy_in(TMP_.p, x, n);
+        launch(C_FB, k_fbstep<T>, grid, TMP_.p, (const T*)nullptr, (T)gam, P, D_.p, (T*)nullptr, n,
+               parts_.p, (int)SL_GSUM);
+        gather(SL_GSUM, 3, 0u);
+        auto v = collect({SL_GSUM}, 0u);
+        *gz = (double)g_value(v[0]);
+        copy_out(z, D_.p, n);
+    }
+
+    void eval_lbfgs(int m, const void* S, const void* Y, const void* v, void* d) override {
+        if (m < 0 || m > MAX_MEM) throw Error(BZ_ERR_ARG, "bad pair count");
+        active = false;
+        M = std::max(1, m);
+        alloc_history();
+        lbfgs_reset_all();
+        rc = 0; xc = 0;
+        const T* Sh = (const T*)S; const T* Yh = (const T*)Y;
+        for (int i = 0; i < m; ++i) {   // oldest first, as update! would have seen them
+            const int slot = spare;
+            copy_in(S_[slot].p, Sh + (size_t)i * n, n);
+            copy_in(Y_[slot].p, Yh + (size_t)i * n, n);
+            launch(C_MISC, k_dot<T>, grid, (const T*)S_[slot].p, (const T*)Y_[slot].p, T(1), n, parts_.p, (int)SL_YS);
+            launch(C_MISC, k_dot<T>, grid, (const T*)Y_[slot].p, (const T*)Y_[slot].p, T(1), n, parts_.p, (int)SL_YTY);
+            gather(SL_YS, 2, 0u);
+            auto r = collect({SL_YS, SL_YTY}, 0u);
+            lbfgs_insert((T)r[0], (T)r[1]);
+        }
+        // d = H * v  == two-loop applied to -(-v)
+        std::vector<T> neg(n);
+        const T* vh = (const T*)v;
+        for (int64_t i = 0; i < n; ++i) neg[i] = -vh[i];
+        copy_in(RES_[rc].p, neg.data(), n);
+        TailArgs<T> t = two_loop();
+        launch(C_TWOLOOP, k_axpy_dot<T>, grid, t, (const T*)nullptr, (const T*)nullptr, D_.p, n,
+               parts_.p, 0);
+        copy_out(d, D_.p, n);
+    }
+
+    void profile_enable(bool on) override { prof_on = on; }
+    void profile_reset() override {
+        drain_prof();
+        for (int c = 0; c < BZ_NUM_KERNEL_CATEGORIES; ++c) { prof_ms[c] = 0; prof_n[c] = 0; }
+    }
+    void profile_get(int cat, int64_t* launches, double* ms) override {
+        if (cat < 0 || cat >= BZ_NUM_KERNEL_CATEGORIES) throw Error(BZ_ERR_ARG, "bad category");
+        drain_prof();
+        *launches = prof_n[cat];
+        *ms = prof_ms[cat];
+    }
+
+    // ------------------------------------------------------- alps (alps.jl:7-117)
+    void alps(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0, const void* y0,
+              void* xo, void* yo, void* so, void* muo, bz_alps_stats* st) override {
+        auto t0 = std::chrono::steady_clock::now();
+        const T epsT = std::numeric_limits<T>::epsilon();
+        T* x = X_[0].p;
+        copy_in(TMP_.p, x0, n);
+        // prox!(x, gFun, x0, eps(T))                                   alps.jl:38
+        launch(C_FB, k_fbstep<T>, grid, (const T*)TMP_.p, (const T*)nullptr, epsT, P, x, (T*)nullptr, n,
+               parts_.p, (int)SL_GSUM);
+        gather(SL_GSUM, 3, 0u);
+        // objx = f(x) + gFun.gz                                        alps.jl:39
+        launch(C_MISC, k_fvalue_elem<T>, grid, (const T*)x, P, n, parts_.p, (int)SL_AUX);
+        gather(SL_AUX, 1, 0u);
+        auto v0 = collect({SL_GSUM, SL_AUX}, 0u);
+        T gz0 = g_value(v0[0]);
+        T objx = T(v0[1]) + gz0;
+        // eval!(cx,c,x); proj!(s,D,cx); default_penalty_parameter!     alps.jl:40-42
+        const double denom = std::max(1.0, (double)objx);
+        launch(C_MISC, k_penalty_init<T>, grid_y, (const T*)x /* cx = x */, P, denom, sproj_.p, mu_.p, ny);
+        copy_in(ymul_.p, y0, ny);                                    // y .= y0
+        double norm_res_prim = 0, norm_res_prim_old = 0;
+        bool have_old = false, have_res = false;
+        int64_t tot_it = 0, tot_inner = 0;
+        double inner_tol = ao.inner_tol;
+        bool solved = false, tired = tot_it >= ao.maxit, broken = std::isnan((double)objx);
+        if (ao.verbose) {
+            std::printf("[ Info: initial inner tolerance %g\n", inner_tol);
+        }
+        bool can_stop = solved || tired || broken;
+        bz_panoc_opts po2 = po;
+        while (!can_stop) {
+            ++tot_it;
+            // dual_safeguard(y, cx)                                    alps.jl:62
+            launch(C_MISC, k_clamp_scale<T>, grid_y, ymul_.p, -1e20, 1e20, T(1), 1, ny);
+            po2.tol = inner_tol;                                     // alps.jl:64
+            po2.verbose = ao.verbose;
+            aug_lag_update();                                        // alps.jl:65
+            begin_dev(po2, x);                                       // alps.jl:66
+            run_to_completion();
+            const int64_t sub_it = k_;
+            x = Z_[zc].p;                                            // x .= sub_sol
+            objx = fraw_last + g_z;                                  // alps.jl:68
+            tot_inner += sub_it;
+            const bool sub_solved = sub_it < ao.subsolver_maxit;     // alps.jl:70
+            // dual update + primal residual                          alps.jl:72-84
+            launch(C_MISC, k_dual_update<T>, grid_y, (const T*)x, P, ymul_.p, sproj_.p, ny, parts_.p,
+                   (int)SL_OUTER);
+            gather(SL_OUTER, 1, 1u);
+            auto r = collect({SL_OUTER}, 1u);
+            norm_res_prim_old = norm_res_prim; have_old = have_res;
+            norm_res_prim = r[0]; have_res = true;
+            solved = (inner_tol <= ao.tol_dual && sub_solved) && (norm_res_prim <= ao.tol_prim);
+            tired = tot_it >= ao.maxit;
+            broken = std::isnan((double)objx);
+            can_stop = solved || tired || broken;
+            if (!can_stop) {
+                if (have_old &&
+                    norm_res_prim > std::max(ao.theta_penalty * norm_res_prim_old, ao.tol_prim)) {
+                    launch(C_MISC, k_clamp_scale<T>, grid_y, mu_.p, 0.0, 0.0, (T)ao.kappa_penalty, 0, ny);
+                }
+                inner_tol = std::max(ao.kappa_tol * inner_tol, ao.tol_dual);
+            }
+            // next subproblem starts from x (kept in the z buffer): copy to a state buffer
+            if (!can_stop) {
+                BZ_HIP(hipMemcpyAsync(X_[0].p, x, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+                x = X_[0].p;
+            }
+        }
+        copy_out(xo, x, n);
+        copy_out(yo, ymul_.p, ny);
+        copy_out(so, sproj_.p, ny);
+        copy_out(muo, mu_.p, ny);
+        if (st) {
+            st->tot_it = tot_it; st->tot_inner_it = tot_inner;
+            st->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            st->status = solved ? 0 : (tired ? 1 : (broken ? 2 : 3));
+            st->inner_tol = inner_tol; st->norm_res_prim = norm_res_prim;
+            st->objective = (double)objx;
+        }
+    }
+
+   private:
+    // ------------------------------------------------------------ plumbing
+    Ctx* ctx;
+    bz_problem_desc desc;
+    int64_t n, ny;
+    int grid = 1, grid_y = 1;
+    ElemParams<T> P;
+    DBuf<T> q_, b_, gu_, glo_, ghi_, dlo_, dhi_, mu_, muy_, ymul_, sproj_;
+    DBuf<T> X_[3], RES_[2], Z_[2], GX_, GZ_, D_, TMP_;
+    std::vector<DBuf<T>> S_, Y_;
+    DBuf<double> parts_, alphas_, send_, recv_;
+    double* host_out_ = nullptr;
+    double* host_out_dev_ = nullptr;
+    int grp_first[SL_COUNT], grp_cnt[SL_COUNT];
+
+    // solver state (host scalars)
+    bz_panoc_opts opt{};
+    bool active = false, fused_ok = false, gx_valid = false, gz_valid = false;
+    int xc = 0, rc = 0, zc = 0;
+    T alpha = T(0.95), beta = T(0.5), min_gamma = T(1e-7), musqy = T(0);
+    T gamma = T(0), tau = T(0), f_x = T(0), g_z = T(0), dot_gr = T(0), ss_res = T(0);
+    T f_z_al = T(0), fraw_last = T(0), last_ys = T(0), fbe_last = T(0);
+    double stop_norm_ = 0;
+    int64_t k_ = 0, n_grad = 0, n_prox = 0, n_bt = 0, n_halv = 0, n_fused = 0, n_skips = 0;
+    int last_nbt = 0;
+    bool last_fused = false;
+    std::chrono::steady_clock::time_point t_begin;
+    // L-BFGS ring: M+1 physical slots, `order` newest first, `spare` receives the candidate pair
+    int M = 5;
+    std::deque<int> order;
+    std::vector<int> freeslots;
+    int spare = 0;
+    T ys_[MAX_MEM + 1];
+    T H = T(1);
+
+    // profiling
+    struct ProfRec { int cat; hipEvent_t a, b; };
+    bool prof_on = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[BZ_NUM_KERNEL_CATEGORIES] = {0};
+    int64_t prof_n[BZ_NUM_KERNEL_CATEGORIES] = {0};
+
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e; BZ_HIP(hipEventCreate(&e)); return e;
+    }
+    void drain_prof() {
+        if (prof_recs.empty()) return;
+        BZ_HIP(hipStreamSynchronize(ctx->stream));
+        for (auto& r : prof_recs) {
+            float ms = 0; BZ_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+            prof_ms[r.cat] += ms; prof_n[r.cat] += 1;
+            ev_pool.push_back(r.a); ev_pool.push_back(r.b);
+        }
+        prof_recs.clear();
+    }
+
+    template <class K, class... A> void launch(int cat, K kernel, int g, A... args) {
+        ProfRec r{cat, nullptr, nullptr};
+        if (prof_on) { r.a = get_event(); r.b = get_event(); BZ_HIP(hipEventRecord(r.a, ctx->stream)); }
+        hipLaunchKernelGGL(kernel, dim3(g), dim3(BLOCK), 0, ctx->stream, args...);
+        if (prof_on) {
+            BZ_HIP(hipEventRecord(r.b, ctx->stream));
+            prof_recs.push_back(r);
+            if (prof_recs.size() > 8192) drain_prof();
+        }
+        BZ_HIP(hipGetLastError());
+    }
+
+    void upload(DBuf<T>& dst, const void* src, int64_t cnt) {
+        dst.alloc(cnt);
+        copy_in(dst.p, src, cnt);
+    }
+    void copy_in(T* dst, const void* src, int64_t cnt) {
+        if (!src) throw Error(BZ_ERR_ARG, "null input pointer");
+        BZ_HIP(hipMemcpyAsync(dst, src, cnt * sizeof(T), hipMemcpyDefault, ctx->stream));
+        BZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    void copy_out(void* dst, const T* src, int64_t cnt) {
+        if (!dst) throw Error(BZ_ERR_ARG, "null output pointer");
+        BZ_HIP(hipMemcpyAsync(dst, src, cnt * sizeof(T), hipMemcpyDefault, ctx->stream));
+        BZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    void require_active() const {
+        if (!active) throw Error(BZ_ERR_STATE, "no solve in progress (call bz_panoc_begin first)");
+    }
+
+    // multi-GPU: fold this rank's block partials of slots [first, first+cnt) and all-gather
+    void gather(int first, int cnt, unsigned maxmask) {
+        if (ctx->nranks <= 1) return;
+        launch(C_GATHER, k_pack, 1, (const double*)parts_.p, grid, first, cnt, maxmask, send_.p);
+        BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
+                              ctx->comm, ctx->stream));
+        for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
+    }
+    ScalarSrc src(int slot) const {
+        if (ctx->nranks <= 1) return ScalarSrc{parts_.p + (size_t)slot * PSTRIDE, grid, 1};
+        const int f = grp_first[slot], c = grp_cnt[slot];
+        return ScalarSrc{recv_.p + (size_t)f * ctx->nranks + (slot - f), ctx->nranks, c};
+    }
+    // fold the listed slots (bit i of maxmask: i-th listed slot is a max) and read them back
+    std::vector<double> collect(std::initializer_list<int> slots, unsigned maxmask) {
+        CollectArgs a;
+        a.n = 0; a.maxmask = maxmask;
+        for (int s : slots) {
+            a.src[a.n] = src(s);
+            // partials of slots produced with the y-grid have grid_y entries; identical when c = I
+            ++a.n;
+        }
+        launch(C_COLLECT, k_collect, 1, a, host_out_dev_);
+        BZ_HIP(hipStreamSynchronize(ctx->stream));
+        return std::vector<double>(host_out_, host_out_ + a.n);
+    }
+
+    T al_value(double fsum, double pensum) const {   // auglagfun.jl:78,81-82
+        T lx = T(0.5) * T(pensum);
+        lx += T(fsum);
+        lx -= musqy;
+        return lx;
+    }
+    T g_value(double gsum) const {
+        switch (desc.g_kind) {
+        case BZ_G_NORM_L1: case BZ_G_NORM_L1_NONNEG: case BZ_G_NORM_L1_BOX:
+            return P.g_lambda * T(gsum);
+        default: return T(0);
+        }
+    }
+
+    // gradient!(dlx, al, x) on the device; partials -> slot0 (f terms), slot0+1 (t^2/mu)
+    void algrad(const T* x, T* grad, int slot0) {
+        launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0);
+        gather(slot0, 2, 0u);
+    }
+
+    // AugLagUpdate!(al, mu, y)  (auglagfun.jl:91-101) on the device copies mu_, ymul_
+    void aug_lag_update() {
+        launch(C_MISC, k_muy<T>, grid_y, (const T*)mu_.p, (const T*)ymul_.p, muy_.p, ny, parts_.p,
+               (int)SL_OUTER);
+        gather(SL_OUTER, 2, 2u);
+        auto v = collect({SL_OUTER, SL_OUTER + 1}, 2u);
+        if (v[1] > 0.0) throw Error(BZ_ERR_MU, "parameters `mu` must be positive");
+        musqy = T(0.5) * T(v[0]);
+    }
+
+    // --------------------------------------------------------------- L-BFGS
+    void alloc_history() {
+        if ((int)S_.size() == M + 1) return;
+        S_ = std::vector<DBuf<T>>(M + 1);
+        Y_ = std::vector<DBuf<T>>(M + 1);
+        for (int i = 0; i <= M; ++i) { S_[i].alloc(n); Y_[i].alloc(n); }
+    }
+    void lbfgs_reset_all() {
+        order.clear(); freeslots.clear();
+        spare = 0;
+        for (int i = M; i >= 1; --i) freeslots.push_back(i);
+        H = T(1);
+    }
+    void lbfgs_reset() {                 // reset!(H): currmem = curridx = 0, H = 1
+        for (int s : order) freeslots.push_back(s);
+        order.clear();
+        H = T(1);
+    }
+    void lbfgs_insert(T ys, T yty) {     // update!(H, s, y) when <s,y> > 0
+        order.push_front(spare);
+        ys_[spare] = ys;
+        if ((int)order.size() > M) { spare = order.back(); order.pop_back(); }
+        else { spare = freeslots.back(); freeslots.pop_back(); }
+        H = ys / yty;
+    }
+
+    // d = H(-res) up to the last axpy, which the caller fuses with what follows
+    TailArgs<T> two_loop() {
+        TailArgs<T> t;
+        std::memset(&t, 0, sizeof(t));
+        t.alphas = alphas_.p;
+        const int m = (int)order.size();
+        const T* res = RES_[rc].p;
+        if (m == 0) {
+            t.in = res; t.v = nullptr; t.sgn = T(-1); t.mode = 2; t.apply_H = 1; t.H = H;
+            t.src = ScalarSrc{parts_.p, 0, 1}; t.ys = T(1);
+            return t;
+        }
+        launch(C_TWOLOOP, k_dot<T>, grid, (const T*)S_[order[0]].p, res, T(-1), n, parts_.p, SL_LOOP1 + 0);
+        gather(SL_LOOP1 + 0, 1, 0u);
+        for (int j = 0; j + 1 < m; ++j) {        // loop 1: d -= alpha_j y_j ; <s_{j+1}, d>
+            TailArgs<T> a = t;
+            a.in = (j == 0) ? res : (const T*)D_.p; a.sgn = (j == 0) ? T(-1) : T(1);
+            a.v = Y_[order[j]].p; a.mode = 0; a.j = j; a.apply_H = 0; a.H = T(1);
+            a.src = src(SL_LOOP1 + j); a.ys = ys_[order[j]];
+            launch(C_TWOLOOP, k_axpy_dot<T>, grid, a, (const T*)S_[order[j + 1]].p, (const T*)nullptr,
+                   D_.p, n, parts_.p, SL_LOOP1 + j + 1);
+            gather(SL_LOOP1 + j + 1, 1, 0u);
+        }
+        {                                          // d = H (d - alpha_{m-1} y_{m-1}) ; <y_{m-1}, d>
+            TailArgs<T> a = t;
+            const int j = m - 1;
+            a.in = (m == 1) ? res : (const T*)D_.p; a.sgn = (m == 1) ? T(-1) : T(1);
+            a.v = Y_[order[j]].p; a.mode = 0; a.j = j; a.apply_H = 1; a.H = H;
+            a.src = src(SL_LOOP1 + j); a.ys = ys_[order[j]];
+            launch(C_TWOLOOP, k_axpy_dot<T>, grid, a, (const T*)Y_[order[j]].p, (const T*)nullptr, D_.p,
+                   n, parts_.p, SL_LOOP2 + j);
+            gather(SL_LOOP2 + j, 1, 0u);
+        }
+        for (int j = m - 1; j >= 1; --j) {         // loop 2: d += (alpha_j - beta_j) s_j ; <y_{j-1}, d>
+            TailArgs<T> a = t;
+            a.in = D_.p; a.sgn = T(1); a.v = S_[order[j]].p; a.mode = 1; a.j = j; a.apply_H = 0;
+            a.H = T(1); a.src = src(SL_LOOP2 + j); a.ys = ys_[order[j]];
+            launch(C_TWOLOOP, k_axpy_dot<T>, grid, a, (const T*)Y_[order[j - 1]].p, (const T*)nullptr,
+                   D_.p, n, parts_.p, SL_LOOP2 + j - 1);
+            gather(SL_LOOP2 + j - 1, 1, 0u);
+        }
+        t.in = D_.p; t.sgn = T(1); t.v = S_[order[0]].p; t.mode = 1; t.j = 0; t.apply_H = 0; t.H = T(1);
+        t.src = src(SL_LOOP2 + 0); t.ys = ys_[order[0]];
+        return t;
+    }
+
+    // ------------------------------------------------ Base.iterate(iter)  (k = 1)
+    void begin_dev(const bz_panoc_opts& o, const T* x0_dev) {
+        opt = o;
+        if (o.lbfgs_memory < 1 || o.lbfgs_memory > MAX_MEM)
+            throw Error(BZ_ERR_ARG, "lbfgs_memory must be in 1..16");
+        if (o.max_backtracks < 1) throw Error(BZ_ERR_ARG, "max_backtracks must be >= 1");
+        M = o.lbfgs_memory;
+        alloc_history();
+        lbfgs_reset_all();
+        alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
+        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY &&
+                   (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
+        t_begin = std::chrono::steady_clock::now();
+        k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;
+        last_nbt = 0; last_fused = false; tau = T(0); last_ys = T(0); fbe_last = T(0);
+        xc = 0; rc = 0; zc = 0;
+        if (x0_dev != X_[0].p)
+            BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        const T eps = std::numeric_limits<T>::epsilon();
+        T* x = X_[xc].p;
+        // grad_f_x, f_x = gradient(f, x)
+        algrad(x, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+        // gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad_f_x)
+        launch(C_MISC, k_add_scalar<T>, grid, (const T*)x, T(1), TMP_.p, n);
+        algrad(TMP_.p, GZ_.p, SL_FZ); ++n_grad;
+        launch(C_MISC, k_diff_ss2<T>, grid, (const T*)GZ_.p, (const T*)GX_.p, (const T*)TMP_.p, (const T*)x, n,
+               parts_.p, (int)SL_AUX);
+        gather(SL_AUX, 2, 0u);
+        {
+            auto v = collect({SL_FXD, SL_PXD, SL_AUX, SL_AUX + 1}, 0u);
+            f_x = al_value(v[0], v[1]);
+            const T Lest = std::sqrt(T(v[2])) / std::sqrt(T(v[3]));
+            gamma = alpha / Lest;
+        }
+        // y = x - gamma grad ; z, g_z = prox(g, y, gamma) ; res = x - z ; backtrack_stepsize!
+        T f_z = T(0);
+        for (;;) {
+            launch(C_FB, k_fbstep<T>, grid, (const T*)x, (const T*)GX_.p, gamma, P, Z_[zc].p, RES_[rc].p, n,
+                   parts_.p, (int)SL_GSUM);
+            gather(SL_GSUM, 3, 0u);
+            ++n_prox;
+            algrad(Z_[zc].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
+            auto v = collect({SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ}, 0u);
+            g_z = g_value(v[0]); dot_gr = T(v[1]); ss_res = T(v[2]);
+            f_z = al_value(v[3], v[4]); fraw_last = T(v[3]); f_z_al = f_z;
+            const T nr = std::sqrt(ss_res);
+            const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
+            const T tol = T(10) * eps * (T(1) + std::abs(f_z));
+            if (f_z > f_z_upp + tol && gamma >= min_gamma) {
+                gamma = gamma / T(2); ++n_halv;
+                continue;
+            }
+            break;
+        }
+        if (gamma < min_gamma)
+            std::fprintf(stderr, "Warning: stepsize `gamma` became too small (%g)\n", (double)gamma);
+        launch(C_UPDATE, k_update<T>, grid, (const T*)x, (const T*)nullptr, (const T*)RES_[rc].p,
+               (const T*)nullptr, (const T*)GX_.p, (const T*)GZ_.p, gamma, (T*)nullptr, (T*)nullptr, n,
+               parts_.p, (int)SL_YS);
+        gather(SL_YS, 3, 4u);
+        auto v = collect({SL_STOP}, 1u);
+        stop_norm_ = v[0];
+        active = true;
+    }
+
+    void run_to_completion() {
+        for (;;) {
+            const bool stop = should_stop();
+            if (opt.verbose && (stop || (opt.freq > 0 && k_ % opt.freq == 0))) display();
+            if (stop) break;
+            step();
+        }
+    }
+
+    void display() {
+        launch(C_MISC, k_absmax<T>, grid, (const T*)RES_[rc].p, n, parts_.p, (int)SL_AUX);
+        gather(SL_AUX, 1, 1u);
+        auto v = collect({SL_AUX}, 1u);
+        std::printf("%5lld | %.3e | %.3e | %.3e\n", (long long)k_, (double)gamma, v[0] / (double)gamma,
+                    (double)tau);
+    }
+
+    // ---------------------------------------- Base.iterate(iter, state)  (k += 1)
+   public:
+    void step() override {
+        require_active();
+        ++k_;
+        const T eps = std::numeric_limits<T>::epsilon();
+        const int max_bt = opt.max_backtracks;
+        // FBE at the current state
+        const T nr0 = std::sqrt(ss_res);
+        const T FBE_x = (f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr0 * nr0)) + g_z;
+        fbe_last = FBE_x;
+        // direction d = H(-res): all but the last axpy
+        TailArgs<T> tail = two_loop();
+        tau = T(1);
+        const int xp = xc, xd = (xc + 1) % 3, xb = (xc + 2) % 3;
+        const int rp = rc, rn = 1 - rc, zp = zc, zn = 1 - zc;
+        int xcur = xd;
+        bool have_trial = false, fused_this = false;
+        if (fused_ok) {
+            launch(C_FUSED, k_fused_sep<T>, grid, tail, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, gamma,
+                   X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, (T*)nullptr, (T*)nullptr, n,
+                   parts_.p, (int)SL_TRIAL);
+            gather(SL_TRIAL, 10, 1u << 9);
+            have_trial = true; fused_this = true; gx_valid = false; gz_valid = false;
+            n_grad += 2; n_prox += 1;
+        } else {
+            // x_d = x + d ; gradient at x_d ; state.x = x_d
+            launch(C_TWOLOOP, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
+                   parts_.p, 0);
+            algrad(X_[xd].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+        }
+        T sigma = beta * (T(0.5) / gamma) * (T(1) - alpha);
+        const T tol0 = T(10) * eps * (T(1) + std::abs(FBE_x));
+        const T threshold = FBE_x - sigma * (nr0 * nr0) + tol0;
+        std::vector<double> v;
+        int nbt = 0;
+        for (int k = 1; k <= max_bt; ++k) {
+            if (!have_trial) {
+                if (!gx_valid) { algrad(X_[xcur].p, GX_.p, SL_FXD); gx_valid = true; }
+                launch(C_FB, k_fbstep<T>, grid, (const T*)X_[xcur].p, (const T*)GX_.p, gamma, P, Z_[zn].p,
+                       RES_[rn].p, n, parts_.p, (int)SL_GSUM);
+                gather(SL_GSUM, 3, 0u);
+                ++n_prox;
+                algrad(Z_[zn].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
+                launch(C_UPDATE, k_update<T>, grid, (const T*)X_[xcur].p, (const T*)X_[xp].p,
+                       (const T*)RES_[rn].p, (const T*)RES_[rp].p, (const T*)GX_.p, (const T*)GZ_.p, gamma,
+                       S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_YS);
+                gather(SL_YS, 3, 4u);
+            }
+            have_trial = false;
+            v = collect({SL_FXD, SL_PXD, SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_YS, SL_YTY, SL_STOP},
+                        1u << 9);
+            f_x = al_value(v[0], v[1]);
+            g_z = g_value(v[2]); dot_gr = T(v[3]); ss_res = T(v[4]);
+            const T f_z = al_value(v[5], v[6]);
+            fraw_last = T(v[5]); f_z_al = f_z;
+            const T nr = std::sqrt(ss_res);
+            const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
+            const T tol = T(10) * eps * (T(1) + std::abs(f_z));
+            if (f_z > f_z_upp + tol && gamma >= min_gamma) {
+                gamma = gamma * T(0.5); ++n_halv;
+                if (gamma < min_gamma)
+                    std::fprintf(stderr, "Warning: stepsize `gamma` became too small (%g)\n", (double)gamma);
+                sigma = sigma * T(2);   // (as upstream: sigma is updated, the threshold is kept)
+                lbfgs_reset();
+                fused_this = false;
+                continue;
+            }
+            const T FBE_new = f_z_upp + g_z;
+            if (FBE_new <= threshold || k >= max_bt) break;
+            tau = (k >= max_bt - 1) ? T(0) : tau / T(2);
+            ++nbt; ++n_bt;
+            launch(C_MISC, k_blend<T>, grid, (const T*)X_[xd].p, (const T*)Z_[zp].p, tau, T(1) - tau,
+                   X_[xb].p, n);
+            xcur = xb;
+            algrad(X_[xb].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+            fused_this = false;
+        }
+        // update!(H, x - x_prev, res - res_prev): the pair sits in the spare slot
+        const T ys = T(v[7]), yty = T(v[8]);
+        last_ys = ys;
+        if (ys > T(0)) lbfgs_insert(ys, yty); else ++n_skips;
+        stop_norm_ = v[9];
+        xc = xcur; rc = rn; zc = zn;
+        last_nbt = nbt; last_fused = fused_this;
+        if (fused_this) ++n_fused;
+    }
+
+   private:
+    void fill_stats(bz_panoc_stats* st) {
+        std::memset(st, 0, sizeof(*st));
+        st->iters = k_; st->f_z = (double)fraw_last; st->g_z = (double)g_z; st->al_z = (double)f_z_al;
+        st->gamma = (double)gamma; st->tau = (double)tau; st->stop_norm = stop_norm_;
+        st->n_grad = n_grad; st->n_prox = n_prox; st->n_backtracks = n_bt; st->n_gamma_halvings = n_halv;
+        st->n_fused_iters = n_fused; st->n_lbfgs_skips = n_skips;
+        st->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        st->status = std::isnan((double)f_x) ? 2 : ((double)stop_norm_ <= opt.tol ? 0 : 1);
+    }
+};
+
+SolverBase* make_solver(Ctx* ctx, const bz_problem_desc& d) {
+    if (d.dtype == BZ_F64) return new Solver<double>(ctx, d);
+    if (d.dtype == BZ_F32) return new Solver<float>(ctx, d);
+    throw Error(BZ_ERR_ARG, "dtype must be BZ_F64 or BZ_F32");
+}
+
+}  // namespace bz

@@ -1,0 +1,198 @@
+"""Context / problem handles over the C ABI, plus single-node multi-GPU setup."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+from .oracles import lower
+
+_default_ctx = None
+
+
+class Context:
+    """One per process/GPU (bz_ctx).  nranks > 1: x is sharded over the ranks and the
+    reductions' partial scalars are all-gathered with RCCL."""
+
+    def __init__(self, device=0, rank=0, nranks=1, comm_id: bytes | None = None):
+        lib = L.load()
+        o = L.CtxOpts()
+        o.device, o.rank, o.nranks = device, rank, nranks
+        self._id = None
+        if nranks > 1:
+            if comm_id is None or len(comm_id) != 128:
+                raise ValueError("nranks > 1 needs the 128-byte id from unique_id() on rank 0")
+            self._id = C.create_string_buffer(comm_id, 128)
+            o.comm_id = C.cast(self._id, C.c_void_p)
+        h = C.c_void_p()
+        L.check(lib.bz_ctx_create(C.byref(o), C.byref(h)))
+        self._h = h
+        self.device, self.rank, self.nranks = device, rank, nranks
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(L.load().bz_comm_unique_id(buf))
+        return buf.raw
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int32(), C.c_int64()
+        L.check(L.load().bz_device_info(self._h, name, C.byref(cus), C.byref(mem)))
+        return {"arch": name.value.decode(), "cus": cus.value, "mem_bytes": mem.value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.load().bz_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(device=int(os.environ.get("BZ_DEVICE", "0")))
+    return _default_ctx
+
+
+def set_default_context(ctx: Context):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+def shard_bounds(n: int, rank: int, nranks: int, align: int = 256):
+    """Contiguous block partition of [0, n) over nranks, boundaries aligned to `align`
+    elements.  Returns (start, stop)."""
+    per = -(-n // nranks)
+    per = -(-per // align) * align
+    start = min(n, rank * per)
+    stop = min(n, start + per)
+    return start, stop
+
+
+class Problem:
+    """bz_problem: the lowered (f, g, c, D) with its device-resident data and solver state."""
+
+    def __init__(self, f, g, c, D, n, ny, dtype, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self.n, self.ny, self.dtype = int(n), int(ny), np.dtype(dtype)
+        desc, keep = lower(f, g, c, D, self.n, self.ny, self.dtype)
+        h = C.c_void_p()
+        L.check(L.load().bz_problem_create(self.ctx._h, C.byref(desc), C.byref(h)))
+        del keep
+        self._h = h
+
+    # -- helpers
+    def _in(self, a, n):
+        v = np.ascontiguousarray(a, dtype=self.dtype)
+        if v.shape != (n,):
+            raise ValueError(f"expected a vector of length {n}, got shape {v.shape}")
+        return v
+
+    def set_multipliers(self, mu, y):
+        mu, y = self._in(mu, self.ny), self._in(y, self.ny)
+        L.check(L.load().bz_problem_set_multipliers(self._h, mu.ctypes.data, y.ctypes.data))
+
+    def panoc_solve(self, opts: L.PanocOpts, x0):
+        x0 = self._in(x0, self.n)
+        out = np.empty(self.n, self.dtype)
+        st = L.PanocStats()
+        L.check(L.load().bz_panoc_solve(self._h, C.byref(opts), x0.ctypes.data, out.ctypes.data, C.byref(st)))
+        return out, st
+
+    def panoc_begin(self, opts: L.PanocOpts, x0):
+        x0 = self._in(x0, self.n)
+        L.check(L.load().bz_panoc_begin(self._h, C.byref(opts), x0.ctypes.data))
+
+    def panoc_step(self):
+        L.check(L.load().bz_panoc_step(self._h))
+
+    def panoc_finish(self):
+        out = np.empty(self.n, self.dtype)
+        st = L.PanocStats()
+        L.check(L.load().bz_panoc_finish(self._h, out.ctypes.data, C.byref(st)))
+        return out, st
+
+    def panoc_stats(self):
+        st = L.PanocStats()
+        L.check(L.load().bz_panoc_finish(self._h, None, C.byref(st)))
+        return st
+
+    SCALAR_NAMES = ("k", "gamma", "tau", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys",
+                    "lbfgs_mem", "lbfgs_H", "al_z", "f_z", "n_backtracks", "fused", "FBE")
+
+    def panoc_scalars(self):
+        buf = (C.c_double * 16)()
+        L.check(L.load().bz_panoc_scalars(self._h, buf))
+        return dict(zip(self.SCALAR_NAMES, list(buf)))
+
+    def panoc_vector(self, which):
+        idx = {"x": 0, "z": 1, "res": 2, "grad_x": 3, "grad_z": 4}[which]
+        out = np.empty(self.n, self.dtype)
+        L.check(L.load().bz_panoc_vector(self._h, idx, out.ctypes.data))
+        return out
+
+    def alps_solve(self, aopts: L.AlpsOpts, popts: L.PanocOpts, x0, y0):
+        x0, y0 = self._in(x0, self.n), self._in(y0, self.ny)
+        x = np.empty(self.n, self.dtype)
+        y, s, mu = (np.empty(self.ny, self.dtype) for _ in range(3))
+        st = L.AlpsStats()
+        L.check(L.load().bz_alps_solve(self._h, C.byref(aopts), C.byref(popts), x0.ctypes.data, y0.ctypes.data,
+                                       x.ctypes.data, y.ctypes.data, s.ctypes.data, mu.ctypes.data, C.byref(st)))
+        return x, y, s, mu, st
+
+    def eval_al_gradient(self, x):
+        x = self._in(x, self.n)
+        g = np.empty(self.n, self.dtype)
+        vals = (C.c_double * 3)()
+        L.check(L.load().bz_eval_al_gradient(self._h, x.ctypes.data, g.ctypes.data, vals))
+        return g, tuple(vals)
+
+    def eval_prox(self, x, gamma):
+        x = self._in(x, self.n)
+        z = np.empty(self.n, self.dtype)
+        gz = C.c_double()
+        L.check(L.load().bz_eval_prox(self._h, x.ctypes.data, float(gamma), z.ctypes.data, C.byref(gz)))
+        return z, gz.value
+
+    def eval_lbfgs(self, S, Y, v):
+        v = self._in(v, self.n)
+        m = len(S)
+        Sa = np.ascontiguousarray(S, dtype=self.dtype).reshape(m, self.n) if m else None
+        Ya = np.ascontiguousarray(Y, dtype=self.dtype).reshape(m, self.n) if m else None
+        d = np.empty(self.n, self.dtype)
+        L.check(L.load().bz_eval_lbfgs(self._h, m, Sa.ctypes.data if m else None, Ya.ctypes.data if m else None,
+                                       v.ctypes.data, d.ctypes.data))
+        return d
+
+    def profile_enable(self, on=True):
+        L.check(L.load().bz_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        L.check(L.load().bz_profile_reset(self._h))
+
+    def profile(self):
+        out = {}
+        for i, name in enumerate(L.KERNEL_CATEGORIES):
+            n, ms = C.c_int64(), C.c_double()
+            L.check(L.load().bz_profile_get(self._h, i, C.byref(n), C.byref(ms)))
+            out[name] = {"launches": n.value, "total_ms": ms.value}
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.load().bz_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

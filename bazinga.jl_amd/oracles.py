@@ -1,0 +1,202 @@
+"""The f/g/c/D oracle types of Bazinga.alps that this build lowers to the device.
+
+The reference's oracles are duck-typed Julia structs (README.md:17-20,
+src/Bazinga.jl:7-16).  A device cannot run arbitrary closures, so the host side
+pattern-matches the structured types below and lowers them to a C descriptor
+(`bz_problem_desc`, include/bazinga_hip.h).  Anything else raises
+``UnsupportedOracle`` — there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib as L
+
+
+class UnsupportedOracle(TypeError):
+    pass
+
+
+# ----------------------------------------------------------------- abstract tags
+class ProximableFunction:   # src/Bazinga.jl:7
+    pass
+
+
+class SmoothFunction:       # src/Bazinga.jl:8
+    pass
+
+
+class ClosedSetBase:        # src/Bazinga.jl:9  (abstract type ClosedSet)
+    pass
+
+
+# ------------------------------------------------------------------------- f
+class Zero(ProximableFunction):
+    """src/proxoperators/zero.jl:11-25; usable as f or g."""
+
+
+class DiagQuadratic(ProximableFunction):
+    """f(x) = sum_i x_i (0.5 q_i x_i - b_i) — diagonal special case of
+    ProximalOperators.Quadratic (test/problems/test_nonconvex_qp.jl:14)."""
+
+    def __init__(self, q, b):
+        self.q = np.ascontiguousarray(q)
+        self.b = np.ascontiguousarray(b)
+        if self.q.shape != self.b.shape or self.q.ndim != 1:
+            raise ValueError("q and b must be vectors of equal length")
+
+
+# ------------------------------------------------------------------------- g
+class IndFree(ProximableFunction):
+    """ProximalOperators.IndFree (test_nonconvex_qp.jl:39)."""
+
+
+class NormL1(ProximableFunction):
+    """ProximalOperators.NormL1(lambda) (test_verbose.jl:23, demo/basispursuit.jl:63)."""
+
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")
+        self.lam = float(lam)
+
+
+class NormL1Nonneg(ProximableFunction):
+    """src/proxoperators/normL1Nonneg.jl:9-42"""
+
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("λ must be nonnegative")
+        self.lam = float(lam)
+
+
+class NormL1Box(ProximableFunction):
+    """src/proxoperators/normL1Box.jl:11-39"""
+
+    def __init__(self, lam=1.0, *, u):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")
+        self.u = np.ascontiguousarray(u)
+        if np.any(self.u < 0):
+            raise ValueError("vector u must have nonnegative entries")
+        self.lam = float(lam)
+
+
+class IndBox(ProximableFunction):
+    """ProximalOperators.IndBox(lb, ub) (test_nonconvex_qp.jl:15); scalar or vector bounds."""
+
+    def __init__(self, lb, ub):
+        self.lb = lb
+        self.ub = ub
+        if np.any(np.asarray(lb) > np.asarray(ub)):
+            raise ValueError("bounds must satisfy lb <= ub")
+
+
+# ------------------------------------------------------------------------- c
+class IdentityFunction(SmoothFunction):
+    """test/definitions/identityFunction.jl:3-13"""
+
+
+# ------------------------------------------------------------------------- D
+class ZeroSet(ClosedSetBase):
+    """src/projections/zeroSet.jl:8-20"""
+
+
+class FreeSet(ClosedSetBase):
+    """src/projections/freeSet.jl:8-20"""
+
+
+class IndicatorSet(ClosedSetBase):
+    """src/projections/indicatorSet.jl:4-11"""
+
+    def __init__(self, f):
+        self.f = f
+
+
+def ClosedSet(f):
+    """src/Bazinga.jl:18"""
+    return IndicatorSet(f)
+
+
+# ------------------------------------------------------------------ lowering
+def _vec(a, dtype, n, name):
+    v = np.ascontiguousarray(a, dtype=dtype)
+    if v.shape != (n,):
+        raise ValueError(f"{name} must have length {n}")
+    return v
+
+
+def lower(f, g, c, D, n, ny, dtype):
+    """(f, g, c, D) -> (ProblemDesc, keepalive list).  Raises UnsupportedOracle."""
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        code = L.BZ_F64
+    elif dtype == np.float32:
+        code = L.BZ_F32
+    else:
+        raise UnsupportedOracle(f"eltype {dtype} is not lowered (Float64/Float32 only)")
+    d = L.ProblemDesc()
+    keep = []
+    d.dtype, d.n, d.ny = code, n, ny
+
+    def ptr(a):
+        keep.append(a)
+        return a.ctypes.data
+
+    # f
+    if isinstance(f, Zero):
+        d.f_kind = L.BZ_F_ZERO
+    elif isinstance(f, DiagQuadratic):
+        d.f_kind = L.BZ_F_DIAG_QUADRATIC
+        d.f_q = ptr(_vec(f.q, dtype, n, "q"))
+        d.f_b = ptr(_vec(f.b, dtype, n, "b"))
+    else:
+        raise UnsupportedOracle(f"f of type {type(f).__name__} is not lowered to the device")
+    # g
+    if isinstance(g, (Zero, IndFree)):
+        d.g_kind = L.BZ_G_ZERO
+    elif isinstance(g, NormL1):
+        d.g_kind, d.g_lambda = L.BZ_G_NORM_L1, g.lam
+    elif isinstance(g, NormL1Nonneg):
+        d.g_kind, d.g_lambda = L.BZ_G_NORM_L1_NONNEG, g.lam
+    elif isinstance(g, NormL1Box):
+        d.g_kind, d.g_lambda = L.BZ_G_NORM_L1_BOX, g.lam
+        d.g_u = ptr(_vec(g.u, dtype, n, "u"))
+    elif isinstance(g, IndBox):
+        d.g_kind = L.BZ_G_IND_BOX
+        if np.ndim(g.lb) == 0:
+            d.g_lo = float(g.lb)
+        else:
+            d.g_lo_vec = ptr(_vec(g.lb, dtype, n, "lb"))
+        if np.ndim(g.ub) == 0:
+            d.g_hi = float(g.ub)
+        else:
+            d.g_hi_vec = ptr(_vec(g.ub, dtype, n, "ub"))
+    else:
+        raise UnsupportedOracle(f"g of type {type(g).__name__} is not lowered to the device")
+    # c
+    if isinstance(c, IdentityFunction):
+        d.c_kind = L.BZ_C_IDENTITY
+        if ny != n:
+            raise ValueError("IdentityFunction requires length(y0) == length(x0)")
+    else:
+        raise UnsupportedOracle(f"c of type {type(c).__name__} is not lowered to the device")
+    # D
+    if isinstance(D, ZeroSet):
+        d.D_kind = L.BZ_D_ZERO
+    elif isinstance(D, FreeSet):
+        d.D_kind = L.BZ_D_FREE
+    elif isinstance(D, IndicatorSet) and isinstance(D.f, IndBox):
+        d.D_kind = L.BZ_D_BOX
+        if np.ndim(D.f.lb) == 0:
+            d.D_lo = float(D.f.lb)
+        else:
+            d.D_lo_vec = ptr(_vec(D.f.lb, dtype, ny, "lb"))
+        if np.ndim(D.f.ub) == 0:
+            d.D_hi = float(D.f.ub)
+        else:
+            d.D_hi_vec = ptr(_vec(D.f.ub, dtype, ny, "ub"))
+    elif isinstance(D, IndicatorSet) and isinstance(D.f, IndFree):
+        d.D_kind = L.BZ_D_FREE
+    else:
+        raise UnsupportedOracle(f"D of type {type(D).__name__} is not lowered to the device")
+    return d, keep

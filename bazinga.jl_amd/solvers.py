@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's solver interface for the hot path.
+
+    alps(f, g, c, D, x0, y0; kw...)          src/algorithms/alps.jl:7-117
+    PANOCplus(; kw...)(f=alFun, g=gFun, x0)  the `subsolver` seam, alps.jl:24,64-66
+    AugLagFun / AugLagUpdate                 src/utilities/auglagfun.jl
+    NonsmoothCostFun                         src/utilities/nonsmoothcostfun.jl
+    default_dual_safeguard / default_penalty_parameter   src/utilities/safeguards.jl
+
+Same names, argument meaning, defaults and error behaviour; the arithmetic on
+n-vectors runs in libbazinga_hip.so (HIP kernels, gfx950).  Nothing here falls
+back to a CPU solver: without the library or a GPU these calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib as L
+from .device import Problem, default_context
+from .oracles import UnsupportedOracle
+
+
+class LBFGS:
+    """ProximalAlgorithms.LBFGS(memory) — the only `directions` the shipped scripts select
+    (demo/rosenbrock.jl:103,275)."""
+
+    def __init__(self, memory=5):
+        self.memory = int(memory)
+
+
+# ------------------------------------------------------------------ safeguards
+def default_dual_safeguard(y, cx=None):
+    """src/utilities/safeguards.jl:2-10"""
+    np.clip(y, -1e20, 1e20, out=y)
+    return None
+
+
+def default_penalty_parameter(mu, cx, proj_cx, objx):
+    """src/utilities/safeguards.jl:13-18"""
+    d2 = ((cx - proj_cx) ** 2).astype(np.float64, copy=False)
+    mu[...] = (np.maximum(1.0, 0.5 * d2) / max(1.0, float(objx))).astype(mu.dtype, copy=False)
+    mu[...] = (mu.astype(np.float64, copy=False) * 0.1).astype(mu.dtype, copy=False)
+    mu[...] = np.maximum(1e-8, np.minimum(mu.astype(np.float64, copy=False), 1e8)).astype(mu.dtype, copy=False)
+    return None
+
+
+# --------------------------------------------------------- AL functor wrappers
+class NonsmoothCostFun:
+    """src/utilities/nonsmoothcostfun.jl:1-22 — records gamma and g(z) of the last prox."""
+
+    def __init__(self, g):
+        self.g = g
+        self.gamma = 0.0
+        self.gz = 0.0
+
+
+class AugLagFun:
+    """src/utilities/auglagfun.jl:11-54.  Holds (f, c, D, mu, y) and the scalar caches the
+    outer loop reads back (`fx`, `muy`, `musqy`).  The value/gradient evaluation itself
+    (auglagfun.jl:58-86) happens on the device inside the subsolver."""
+
+    def __init__(self, f, c, D, mu, y, x):
+        if np.any(mu <= 0):
+            raise ValueError("parameters `mu` must be positive")     # auglagfun.jl:33-34
+        self.f, self.c, self.D = f, c, D
+        self.mu, self.y = mu, y
+        self.muy = mu * y
+        self.musqy = x.dtype.type(0.5) * np.sum(self.muy * y)
+        self.fx = x.dtype.type(0)
+        self.n, self.ny, self.dtype = x.shape[0], y.shape[0], x.dtype
+        self._problem = None
+        self._problem_key = None
+
+    def problem(self, g, ctx=None) -> Problem:
+        key = (id(g), id(ctx))
+        if self._problem is None or self._problem_key != key:
+            self._problem = Problem(self.f, g, self.c, self.D, self.n, self.ny, self.dtype, ctx)
+            self._problem_key = key
+        return self._problem
+
+
+def AugLagUpdate(al: AugLagFun, mu, y):
+    """src/utilities/auglagfun.jl:91-101"""
+    if np.any(mu <= 0):
+        raise ValueError("parameters `mu` must be positive")
+    al.mu[...] = mu
+    al.y[...] = y
+    al.muy[...] = al.mu * al.y
+    al.musqy = y.dtype.type(0.5) * np.sum(al.muy * al.y)
+    return None
+
+
+# ----------------------------------------------------------------- inner solver
+class PANOCplus:
+    """Drop-in for ``ProximalAlgorithms.PANOCplus(; kwargs...)`` at the `subsolver` seam.
+
+    ``solver = PANOCplus(tol=..., verbose=...)`` then
+    ``sol, it = solver(f=alFun, g=gFun, x0=x)`` (alps.jl:64-66).  `f` must be an
+    AugLagFun and `g` a NonsmoothCostFun over lowered oracle types."""
+
+    def __init__(self, *, directions=None, maxit=1000, tol=1e-8, verbose=False, freq=10,
+                 minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, ctx=None):
+        self.directions = directions if directions is not None else LBFGS(5)
+        if not isinstance(self.directions, LBFGS):
+            raise UnsupportedOracle("only directions=LBFGS(M) is lowered to the device")
+        self.maxit, self.tol, self.verbose, self.freq = maxit, tol, verbose, freq
+        self.minimum_gamma, self.alpha, self.beta = minimum_gamma, alpha, beta
+        self.max_backtracks, self.fuse, self.ctx = max_backtracks, fuse, ctx
+        self.stats = None
+
+    def c_opts(self) -> L.PanocOpts:
+        o = L.PanocOpts()
+        L.load().bz_panoc_default_opts(C.byref(o))
+        o.tol, o.maxit = float(self.tol), int(min(self.maxit, 2 ** 62))
+        o.freq, o.verbose = int(min(self.freq, 2 ** 31 - 1)), int(bool(self.verbose))
+        o.minimum_gamma, o.alpha, o.beta = float(self.minimum_gamma), float(self.alpha), float(self.beta)
+        o.max_backtracks, o.lbfgs_memory, o.fuse = int(self.max_backtracks), self.directions.memory, int(bool(self.fuse))
+        return o
+
+    def __call__(self, *, f, g, x0):
+        if not isinstance(f, AugLagFun) or not isinstance(g, NonsmoothCostFun):
+            raise UnsupportedOracle("the device subsolver takes f=AugLagFun(...), g=NonsmoothCostFun(...)")
+        prob = f.problem(g.g, self.ctx)
+        prob.set_multipliers(f.mu, f.y)
+        z, st = prob.panoc_solve(self.c_opts(), x0)
+        f.fx = x0.dtype.type(st.f_z)            # side channels read by alps.jl:68
+        g.gz = x0.dtype.type(st.g_z)
+        g.gamma = st.gamma
+        self.stats = st
+        return z, int(st.iters)
+
+
+default_subsolver = PANOCplus
+
+_STATUS = ("first_order", "max_iter", "exception", "unknown")
+
+
+def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol=None, maxit=100,
+         theta_penalty=0.8, kappa_penalty=0.5, kappa_tol=0.1, verbose=False,
+         dual_safeguard=default_dual_safeguard, subsolver=default_subsolver,
+         subsolver_maxit=1_000_000_000, resident=None, ctx=None):
+    """Bazinga.alps (src/algorithms/alps.jl:7-117): same keywords and defaults, same 10-tuple
+    ``(x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu)``
+    (status is the Symbol's name as a string).  x0 / y0 are never mutated.
+
+    resident=True (default when `subsolver` and `dual_safeguard` are the defaults) runs the
+    whole outer loop with device-resident vectors (bz_alps_solve): only scalars cross PCIe
+    between subproblems.  resident=False runs the outer loop below on the host exactly as
+    alps.jl does and enters the device at the `subsolver` seam."""
+    x0 = np.asarray(x0)
+    y0 = np.asarray(y0)
+    T = x0.dtype.type
+    if tol is None:
+        tol = T(1e-6)
+    tol_prim = tol if tol_prim is None else tol_prim
+    tol_dual = tol if tol_dual is None else tol_dual
+    inner_tol = float(np.cbrt(tol_dual)) if inner_tol is None else inner_tol
+    if resident is None:
+        resident = subsolver is default_subsolver and dual_safeguard is default_dual_safeguard
+
+    if resident:
+        sub = subsolver(tol=inner_tol, verbose=verbose)
+        if not isinstance(sub, PANOCplus):
+            raise UnsupportedOracle("resident=True needs a PANOCplus subsolver factory")
+        prob = Problem(f, g, c, D, x0.shape[0], y0.shape[0], x0.dtype, ctx or sub.ctx)
+        ao = L.AlpsOpts()
+        L.load().bz_alps_default_opts(C.byref(ao), L.BZ_F64 if x0.dtype == np.float64 else L.BZ_F32)
+        ao.tol_prim, ao.tol_dual, ao.inner_tol = float(tol_prim), float(tol_dual), float(inner_tol)
+        ao.maxit, ao.theta_penalty, ao.kappa_penalty = int(maxit), float(theta_penalty), float(kappa_penalty)
+        ao.kappa_tol, ao.subsolver_maxit, ao.verbose = float(kappa_tol), int(subsolver_maxit), int(bool(verbose))
+        x, y, s, mu, st = prob.alps_solve(ao, sub.c_opts(), x0, y0)
+        prob.close()
+        return (x, y, int(st.tot_it), int(st.tot_inner_it), st.elapsed_s, _STATUS[st.status],
+                st.inner_tol, st.norm_res_prim if st.tot_it else None, s, mu)
+
+    # ---- host outer loop, device subsolver (line numbers: src/algorithms/alps.jl)
+    start_time = time.time()
+    x = np.empty_like(x0)                                       # :31-35
+    y = np.empty_like(y0)
+    cx = np.empty_like(y0)
+    s = np.empty_like(y0)
+    mu = np.empty_like(y0)
+    gFun = NonsmoothCostFun(g)                                  # :37
+    probe = Problem(f, g, c, D, x0.shape[0], y0.shape[0], x0.dtype, ctx)
+    xz, gz0 = probe.eval_prox(x0, np.finfo(x0.dtype).eps)       # :38  prox!(x, gFun, x0, eps(T))
+    x[...] = xz
+    gFun.gz = T(gz0)
+    # f(x), c(x), proj_D(c(x)): evaluated through the device AL functor with mu = 1, y = 0
+    probe.set_multipliers(np.ones_like(y0), np.zeros_like(y0))
+    _, vals = probe.eval_al_gradient(x)
+    objx = T(vals[1]) + gFun.gz                                 # :39
+    cx[...] = x                                                 # :40 (c = Identity is the only lowered c here)
+    s[...] = _proj_host(D, cx)                                  # :41
+    default_penalty_parameter(mu, cx, s, objx)                  # :42
+    y[...] = y0                                                 # :43
+    probe.close()
+    norm_res_prim = None
+    norm_res_prim_old = None
+    alFun = AugLagFun(f, c, D, mu, y, x)                        # :46
+    tot_it = 0
+    tot_inner_it = 0
+    solved = False
+    tired = tot_it >= maxit
+    broken = bool(np.isnan(objx))
+    if verbose:
+        print(f"[ Info: initial penalty parameters μ ∈ [{mu.min()}, {mu.max()}]")
+        print(f"[ Info: initial inner tolerance {inner_tol}")
+    can_stop = solved or tired or broken
+    while not can_stop:
+        tot_it += 1
+        dual_safeguard(y, cx)                                   # :62
+        sub_solver = subsolver(tol=inner_tol, verbose=verbose)  # :64
+        AugLagUpdate(alFun, mu, y)                              # :65
+        sub_sol, sub_it = sub_solver(f=alFun, g=gFun, x0=x)     # :66
+        x[...] = sub_sol
+        objx = alFun.fx + gFun.gz                               # :68
+        tot_inner_it += sub_it
+        sub_solved = sub_it < subsolver_maxit                   # :70
+        cx[...] = x                                             # :72
+        np.add(cx, alFun.muy, out=y)                            # :74
+        s[...] = _proj_host(D, y)                               # :75
+        y -= s                                                  # :80
+        y /= mu                                                 # :81
+        norm_res_prim_old = norm_res_prim
+        norm_res_prim = np.max(np.abs(cx - s))                  # :84
+        solved = (inner_tol <= tol_dual and sub_solved) and (norm_res_prim <= tol_prim)
+        tired = tot_it >= maxit
+        broken = bool(np.isnan(objx))
+        can_stop = solved or tired or broken
+        if not can_stop:
+            if norm_res_prim_old is None:
+                pass
+            elif norm_res_prim > max(theta_penalty * norm_res_prim_old, tol_prim):
+                mu *= T(kappa_penalty)                          # :97
+            inner_tol = max(kappa_tol * inner_tol, tol_dual)    # :100
+    elapsed_time = time.time() - start_time
+    status = "first_order" if solved else ("max_iter" if tired else ("exception" if broken else "unknown"))
+    return x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu
+
+
+def _proj_host(D, v):
+    """proj!(s, D, v) for the O(ny) outer-loop bookkeeping of the host path (the reference
+    keeps this on the CPU too; the hot path never calls it)."""
+    from .oracles import FreeSet, IndBox, IndFree, IndicatorSet, ZeroSet
+    if isinstance(D, ZeroSet):
+        return np.zeros_like(v)
+    if isinstance(D, FreeSet) or (isinstance(D, IndicatorSet) and isinstance(D.f, IndFree)):
+        return v.copy()
+    if isinstance(D, IndicatorSet) and isinstance(D.f, IndBox):
+        return np.where(v < D.f.lb, D.f.lb, np.where(v > D.f.ub, D.f.ub, v)).astype(v.dtype, copy=False)
+    raise UnsupportedOracle(f"D of type {type(D).__name__} is not lowered")

@@ -1,0 +1,229 @@
+/* bazinga_hip.h — C ABI of libbazinga_hip.so
+ *
+ * MI355X (gfx950) implementation of the PANOCplus inner proximal-gradient solve
+ * that Bazinga.alps runs on every augmented-Lagrangian subproblem.
+ *
+ * The reference (aldma/Bazinga.jl) has no FFI: its seam is the Julia-level
+ * `subsolver` keyword of `alps` (src/algorithms/alps.jl:24,64-66) plus the
+ * duck-typed f/g/c/D oracle protocol (README.md:17-20, src/Bazinga.jl:11-16).
+ * Each entry point below cites the reference interface it replaces; the Julia
+ * `ccall` stubs a maintainer would add are in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all vectors are dense, contiguous, of the
+ *    problem's dtype (double for BZ_F64, float for BZ_F32);
+ *  - unless a function says "device", pointers are HOST pointers; the library
+ *    copies them and never writes through an input pointer (x0/y0 are never
+ *    mutated — pinned by test/problems/test_nonconvex_qp.jl:36);
+ *  - every function returns BZ_OK (0) or a negative error code;
+ *    bz_last_error() gives the message of the calling thread's last failure;
+ *  - handles are not thread-safe; distinct handles are independent;
+ *  - all calls block until their results are on the host.
+ */
+#ifndef BAZINGA_HIP_H
+#define BAZINGA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------ */
+#define BZ_OK                 0
+#define BZ_ERR_ARG           -1   /* bad argument / size / kind combination           */
+#define BZ_ERR_HIP           -2   /* HIP runtime failure (no device, OOM, launch)     */
+#define BZ_ERR_UNSUPPORTED   -3   /* oracle kind not lowered to the device            */
+#define BZ_ERR_STATE         -4   /* call order (e.g. step before begin)              */
+#define BZ_ERR_COMM          -5   /* RCCL failure                                     */
+#define BZ_ERR_MU            -6   /* "parameters `mu` must be positive"
+                                     (src/utilities/auglagfun.jl:33-34,92-93)        */
+
+/* ---- numeric type ----------------------------------------------------- */
+#define BZ_F64 0
+#define BZ_F32 1
+
+/* ---- oracle kinds (the structured types the Julia shim pattern-matches) */
+/* f: smooth cost.  gradient!(dfx,f,x)->fx, f(x)  (src/Bazinga.jl:16)             */
+#define BZ_F_ZERO            0   /* src/proxoperators/zero.jl:13-20                   */
+#define BZ_F_DIAG_QUADRATIC  1   /* sum x_i(0.5 q_i x_i - b_i): diagonal case of
+                                    ProximalOperators.Quadratic (test_nonconvex_qp.jl:14) */
+#define BZ_F_STENCIL5        2   /* 0.5 x'A_h x - b'x, A_h = 5-pt Laplacian, Dirichlet */
+/* g: proximable cost.  prox!(z,g,x,gamma)->g(z)                                     */
+#define BZ_G_ZERO            0   /* zero.jl:22-25, ProximalOperators.Zero / IndFree   */
+#define BZ_G_NORM_L1         1   /* ProximalOperators.NormL1(lambda) (test_verbose.jl:23) */
+#define BZ_G_NORM_L1_NONNEG  2   /* src/proxoperators/normL1Nonneg.jl:29-42           */
+#define BZ_G_NORM_L1_BOX     3   /* src/proxoperators/normL1Box.jl:30-39              */
+#define BZ_G_IND_BOX         4   /* ProximalOperators.IndBox (test_nonconvex_qp.jl:15)*/
+/* c: constraint map.  eval!(cx,c,x), jtprod!(jtv,c,x,v)                             */
+#define BZ_C_IDENTITY        0   /* test/definitions/identityFunction.jl:3-13         */
+#define BZ_C_DENSE_AFFINE    1   /* A x - b, demo/basispursuit.jl:38-49               */
+/* D: closed set.  proj!(s,D,v)                                                      */
+#define BZ_D_ZERO            0   /* src/projections/zeroSet.jl:17-20                  */
+#define BZ_D_FREE            1   /* src/projections/freeSet.jl:17-20                  */
+#define BZ_D_BOX             2   /* ClosedSet(IndBox(lo,hi)), indicatorSet.jl:8-11    */
+
+typedef struct bz_ctx     bz_ctx;
+typedef struct bz_problem bz_problem;
+
+/* ---- context: one per process/GPU ------------------------------------- */
+typedef struct {
+    int32_t device;       /* HIP device ordinal                                      */
+    int32_t rank;         /* this rank, 0..nranks-1                                  */
+    int32_t nranks;       /* 1 = single GPU; >1 = x sharded, scalars all-gathered    */
+    int32_t reserved;
+    const void* comm_id;  /* nranks>1: 128-byte id from bz_comm_unique_id on rank 0  */
+} bz_ctx_opts;
+
+int  bz_comm_unique_id(void* id128);                 /* fills 128 bytes (RCCL id)     */
+int  bz_ctx_create(const bz_ctx_opts* opts, bz_ctx** out);
+void bz_ctx_destroy(bz_ctx* ctx);
+const char* bz_last_error(void);
+const char* bz_version(void);
+/* fills name (<=255 chars), compute-unit count and total device memory in bytes */
+int  bz_device_info(bz_ctx* ctx, char* name256, int32_t* cus, int64_t* mem_bytes);
+
+/* ---- problem descriptor: the f/g/c/D oracles of Bazinga.alps ---------- */
+/* On nranks>1 every rank passes its contiguous shard (n, ny = local sizes).
+ * Scalars (lambda, lo, hi) are used when the matching *_vec pointer is NULL.        */
+typedef struct {
+    int32_t dtype;                 /* BZ_F64 | BZ_F32                                 */
+    int32_t f_kind, g_kind, c_kind, D_kind;
+    int32_t data_on_device;        /* 1: pointers below are device pointers (copied)  */
+    int64_t n;                     /* length of x (local shard)                       */
+    int64_t ny;                    /* length of y / c(x) (local shard)                */
+    /* f */
+    const void* f_q;               /* DIAG_QUADRATIC: q[n]                            */
+    const void* f_b;               /* DIAG_QUADRATIC / STENCIL5: b[n]                 */
+    int64_t     f_grid_nx, f_grid_ny; /* STENCIL5: grid rows, cols (row-major, n=nx*ny) */
+    /* g */
+    double      g_lambda;          /* NORM_L1*: lambda >= 0                           */
+    const void* g_u;               /* NORM_L1_BOX: u[n] >= 0                          */
+    double      g_lo, g_hi;        /* IND_BOX scalar bounds                           */
+    const void* g_lo_vec;          /* IND_BOX vector bounds (or NULL)                 */
+    const void* g_hi_vec;
+    /* c */
+    const void* c_A;               /* DENSE_AFFINE: A[ny][n] row-major                */
+    const void* c_b;               /* DENSE_AFFINE: b[ny]                             */
+    /* D */
+    double      D_lo, D_hi;        /* BOX scalar bounds (+-inf allowed)               */
+    const void* D_lo_vec;          /* BOX vector bounds (or NULL)                     */
+    const void* D_hi_vec;
+} bz_problem_desc;
+
+int  bz_problem_create(bz_ctx* ctx, const bz_problem_desc* desc, bz_problem** out);
+void bz_problem_destroy(bz_problem* p);
+
+/* ---- inner solver: replaces  ProximalAlgorithms.PANOCplus(...)(f=alFun,g=gFun,x0=x)
+ *      at src/algorithms/alps.jl:64-66 ------------------------------------------- */
+typedef struct {
+    double  tol;             /* stop when ||res/gamma - gradL(x) + gradL(z)||_inf <= tol */
+    int64_t maxit;           /* IterativeAlgorithm maxit (default 1000)               */
+    int32_t freq;            /* display frequency when verbose (default 10)           */
+    int32_t verbose;
+    double  minimum_gamma;   /* default 1e-7                                          */
+    double  alpha;           /* default 0.95                                          */
+    double  beta;            /* default 0.5                                           */
+    int32_t max_backtracks;  /* default 20                                            */
+    int32_t lbfgs_memory;    /* directions = LBFGS(M), default 5                      */
+    int32_t fuse;            /* 1: use the single-pass fused kernel when the problem
+                                is separable (elementwise f, c = Identity); 0: always
+                                the generic kernel chain.  Results are bit-identical. */
+    int32_t reserved;
+} bz_panoc_opts;
+
+void bz_panoc_default_opts(bz_panoc_opts* o);
+
+typedef struct {
+    int64_t iters;            /* k returned by the solver (initial state counts as 1) */
+    double  f_z;              /* f at the last point the AL functor was evaluated
+                                 -> alFun.fx  (alps.jl:68)                            */
+    double  g_z;              /* g at the returned z -> gFun.gz (alps.jl:68)          */
+    double  al_z;             /* augmented Lagrangian value at that point             */
+    double  gamma;
+    double  tau;
+    double  stop_norm;
+    int64_t n_grad;           /* AL-gradient evaluations                              */
+    int64_t n_prox;           /* forward-backward (prox) steps                        */
+    int64_t n_backtracks;     /* tau halvings                                         */
+    int64_t n_gamma_halvings;
+    int64_t n_fused_iters;    /* iterations served by the fused fast path             */
+    int64_t n_lbfgs_skips;    /* updates rejected because <s,y> <= 0                  */
+    double  elapsed_s;
+    int32_t status;           /* 0 converged, 1 maxit, 2 NaN encountered              */
+    int32_t reserved;
+} bz_panoc_stats;
+
+/* Multipliers/penalties of the current subproblem:  AugLagUpdate!(alFun, mu, y)
+ * (src/utilities/auglagfun.jl:91-101).  Returns BZ_ERR_MU if any mu <= 0.           */
+int bz_problem_set_multipliers(bz_problem* p, const void* mu, const void* y);
+
+/* One-shot subsolve.  x_out receives state.z.                                      */
+int bz_panoc_solve(bz_problem* p, const bz_panoc_opts* o, const void* x0,
+                   void* x_out, bz_panoc_stats* stats);
+
+/* Step-wise form of the same solve (used by parity tests and bench.py):
+ *   begin  = Base.iterate(iter)           (initial state, k = 1)
+ *   step   = Base.iterate(iter, state)    (k += 1)
+ *   finish = copy out state.z + stats                                               */
+int bz_panoc_begin(bz_problem* p, const bz_panoc_opts* o, const void* x0);
+int bz_panoc_step(bz_problem* p);
+int bz_panoc_finish(bz_problem* p, void* x_out, bz_panoc_stats* stats);
+/* scalars of the current state: out[0..15] =
+ *  {k, gamma, tau, f_x(AL value at x), g_z, <gradL(x),res>, ||res||^2, stop_norm,
+ *   last <s,y>, lbfgs currmem, lbfgs H, AL value at z, f(z), n_backtracks(last it),
+ *   fused(last it), FBE(x)}                                                          */
+int bz_panoc_scalars(bz_problem* p, double* out16);
+/* copies a state vector to the host: which = 0:x 1:z 2:res 3:gradL(x) 4:gradL(z)
+ * (3 and 4 are recomputed on demand when the fused path did not materialise them)   */
+int bz_panoc_vector(bz_problem* p, int32_t which, void* out);
+
+/* ---- outer loop with device-resident vectors: replaces Bazinga.alps
+ *      (src/algorithms/alps.jl:7-117) for lowered oracle kinds ---------------------- */
+typedef struct {
+    double  tol_prim, tol_dual, inner_tol;
+    int64_t maxit;
+    double  theta_penalty, kappa_penalty, kappa_tol;
+    int64_t subsolver_maxit;   /* only the threshold of alps.jl:70                    */
+    int32_t verbose;
+    int32_t reserved;
+} bz_alps_opts;
+
+void bz_alps_default_opts(bz_alps_opts* o, int32_t dtype);
+
+typedef struct {
+    int64_t tot_it, tot_inner_it;
+    double  elapsed_s;
+    int32_t status;            /* 0 :first_order 1 :max_iter 2 :exception 3 :unknown  */
+    int32_t reserved;
+    double  inner_tol, norm_res_prim, objective;
+} bz_alps_stats;
+
+/* x[n], y[ny], s[ny], mu[ny] are outputs (alps.jl:115); x0[n], y0[ny] inputs.       */
+int bz_alps_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po,
+                  const void* x0, const void* y0,
+                  void* x, void* y, void* s, void* mu, bz_alps_stats* stats);
+
+/* ---- single oracle evaluations on the device (kernel-level parity tests) ---- */
+/* gradient!(dlx, al, x) -> lx   (auglagfun.jl:73-86).  vals = {lx, fx, 0.5*sum t^2/mu} */
+int bz_eval_al_gradient(bz_problem* p, const void* x, void* dlx, double* vals3);
+/* prox!(z, gFun, x, gamma) -> g(z)   (nonsmoothcostfun.jl:17-22)                    */
+int bz_eval_prox(bz_problem* p, const void* x, double gamma, void* z, double* gz);
+/* d = H v with the L-BFGS two-loop over m stored pairs (newest last);
+ * S, Y are m*n host arrays, ys[m] = <s_i,y_i>, H0 scalar.                           */
+int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
+                  const void* v, void* d);
+
+/* ---- in-library kernel timing (HIP events on the solver's stream) ----------- */
+/* category: 0 two-loop axpy+dot, 1 fused separable iteration kernel,
+ *           2 AL gradient, 3 forward-backward step, 4 L-BFGS update/stop norm,
+ *           5 scalar collect, 6 all-gather                                          */
+#define BZ_NUM_KERNEL_CATEGORIES 8
+int bz_profile_enable(bz_problem* p, int32_t on);
+int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms);
+int bz_profile_reset(bz_problem* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAZINGA_HIP_H */

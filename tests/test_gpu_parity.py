@@ -1,0 +1,234 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Element-wise outputs must be BIT-EXACT (same operation order, no FMA
+contraction); reduced scalars agree to summation-order rounding (<= 1e-13 relative);
+iterates of the full solve agree within the north-star tolerance 1e-10 relative.
+
+Oracle provenance and its "parity unpinned" status at iterate level: oracle/bazinga_ref.py.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_ITER = 1e-10      # BASELINE.json north_star: iterates within 1e-10 relative
+
+
+def make_cfg2(bz, ref, n, seed_start=0, D="box", dtype=np.float64, g="l1"):
+    d = bz.synth.l1_quadratic(n, start=seed_start, dtype=dtype)
+    f_d = bz.DiagQuadratic(d["q"], d["b"])
+    f_r = ref.DiagQuadratic(d["q"], d["b"])
+    if g == "l1":
+        g_d, g_r = bz.NormL1(d["lam"]), ref.NormL1(d["lam"])
+    elif g == "nonneg":
+        g_d, g_r = bz.NormL1Nonneg(d["lam"]), ref.NormL1Nonneg(d["lam"])
+    elif g == "l1box":
+        u = np.full(n, 0.75, dtype)
+        g_d, g_r = bz.NormL1Box(d["lam"], u=u), ref.NormL1Box(d["lam"], u=u)
+    elif g == "indbox":
+        g_d, g_r = bz.IndBox(-0.5, 0.5), ref.IndBox(dtype(-0.5), dtype(0.5))
+    else:
+        g_d, g_r = bz.Zero(), ref.Zero()
+    if D == "box":
+        D_d, D_r = bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), ref.ClosedSet(ref.IndBox(dtype(d["lo"]), dtype(d["hi"])))
+    elif D == "free":
+        D_d, D_r = bz.FreeSet(), ref.FreeSet()
+    else:
+        D_d, D_r = bz.ZeroSet(), ref.ZeroSet()
+    return d, (f_d, g_d, bz.IdentityFunction(), D_d), (f_r, g_r, ref.IdentityFunction(), D_r)
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 4097, 262147])
+@pytest.mark.parametrize("D", ["box", "free", "zero"])
+def test_al_gradient_bit_exact(bz, ref, n, D):
+    """K1: gradient!(dlx, al, x) (auglagfun.jl:73-86) element-wise bit-exact, value to 1e-13."""
+    d, dev, orc = make_cfg2(bz, ref, n, D=D)
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+    mu = 10.0 ** rng.uniform(-3, 1, n)
+    y = rng.standard_normal(n) * 3
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x)
+    g_ref = np.empty(n)
+    lx = al.gradient(g_ref, x)
+    assert np.array_equal(g_dev, g_ref)
+    assert abs(vals[0] - lx) <= 1e-13 * max(1.0, abs(lx))
+    assert abs(vals[1] - al.fx) <= 1e-13 * max(1.0, abs(al.fx))
+    prob.close()
+
+
+@pytest.mark.parametrize("g", ["l1", "nonneg", "l1box", "indbox", "zero"])
+@pytest.mark.parametrize("n", [3, 1001, 70001])
+def test_prox_bit_exact(bz, ref, n, g):
+    """K3 prox!(z, g, x, gamma): soft-threshold family, element-wise bit-exact."""
+    d, dev, orc = make_cfg2(bz, ref, n, g=g)
+    rng = np.random.default_rng(7 * n + 1)
+    x = rng.standard_normal(n) * 2
+    gamma = 0.37
+    prob = bz.Problem(*dev, n, n, np.float64)
+    z_dev, gz_dev = prob.eval_prox(x, gamma)
+    z_ref = np.empty(n)
+    gz_ref = orc[1].prox(z_ref, x, gamma)
+    assert np.array_equal(z_dev, z_ref)
+    assert abs(gz_dev - gz_ref) <= 1e-13 * max(1.0, abs(gz_ref))
+    prob.close()
+
+
+@pytest.mark.parametrize("m", [0, 1, 2, 5])
+def test_lbfgs_two_loop(bz, ref, m):
+    """K4: d = H v through the chained axpy+dot kernels vs the oracle's two-loop."""
+    n = 5003
+    rng = np.random.default_rng(m)
+    S = [rng.standard_normal(n) for _ in range(m)]
+    Y = [s * rng.uniform(0.5, 2.0, n) for s in S]          # <s,y> > 0
+    v = rng.standard_normal(n)
+    d, dev, orc = make_cfg2(bz, ref, n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    d_dev = prob.eval_lbfgs(S, Y, v)
+    H = ref.LBFGSOperator(max(1, m), v)
+    for s, y in zip(S, Y):
+        H.update(s, y)
+    d_ref = np.empty(n)
+    H.mul(d_ref, v)
+    assert rel(d_dev, d_ref) <= 1e-12
+    prob.close()
+
+
+def run_traces(bz, ref, dev, orc, n, mu, y, x0, iters, fuse=True, minimum_gamma=1e-7, dtype=np.float64):
+    prob = bz.Problem(*dev, n, n, dtype)
+    prob.set_multipliers(mu, y)
+    sub = bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=minimum_gamma, fuse=fuse)
+    prob.panoc_begin(sub.c_opts(), x0)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
+    gF = ref.NonsmoothCostFun(orc[1])
+    it = ref.PANOCplusIteration(al, gF, x0, minimum_gamma=minimum_gamma)
+    st = it.init()
+    rows = []
+    for k in range(iters):
+        sc = prob.panoc_scalars()
+        xd, zd = prob.panoc_vector("x"), prob.panoc_vector("z")
+        rows.append((k + 1, rel(xd, st.x) if np.any(st.x) else float(np.max(np.abs(xd - st.x))),
+                     rel(zd, st.z) if np.any(st.z) else float(np.max(np.abs(zd - st.z))),
+                     sc["gamma"], float(st.gamma), sc["stop_norm"], float(it.stop_norm(st)), sc["fused"]))
+        if k + 1 < iters:
+            prob.panoc_step()
+            st = it.step(st)
+    return prob, st, rows
+
+
+@pytest.mark.parametrize("n", [1000, 4097, 200003])
+@pytest.mark.parametrize("D", ["box", "free"])
+def test_panoc_iterates_match_oracle(bz, ref, n, D):
+    """Per-iteration parity of x and z over the first 30 PANOCplus iterations
+    (two different multiplier settings: y = 0 as in outer iteration 1, and y != 0)."""
+    d, dev, orc = make_cfg2(bz, ref, n, D=D)
+    rng = np.random.default_rng(3)
+    for y in (np.zeros(n), rng.standard_normal(n)):
+        mu = np.full(n, 0.1)
+        x0 = np.zeros(n)
+        prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 30)
+        for k, ex, ez, g_d, g_r, sn_d, sn_r, fused in rows:
+            assert g_d == g_r, f"gamma differs at k={k}"
+            assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k}: {ex} {ez}"
+            assert abs(sn_d - sn_r) <= 1e-9 * max(1.0, sn_r)
+        assert sum(r[-1] for r in rows) >= 20      # the fused fast path actually served the iterations
+        prob.close()
+
+
+@pytest.mark.parametrize("g", ["l1", "nonneg", "l1box", "indbox", "zero"])
+def test_fused_equals_generic_bitwise(bz, ref, g):
+    """The single-pass fused kernel and the generic kernel chain are the same arithmetic:
+    iterates and scalars must be identical to the last bit."""
+    n = 50001
+    d, dev, orc = make_cfg2(bz, ref, n, g=g)
+    rng = np.random.default_rng(11)
+    mu = 10.0 ** rng.uniform(-2, 0, n)
+    y = rng.standard_normal(n)
+    x0 = rng.standard_normal(n) * 0.1
+    out = []
+    for fuse in (True, False):
+        prob = bz.Problem(*dev, n, n, np.float64)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse).c_opts(), x0)
+        for _ in range(25):
+            prob.panoc_step()
+        out.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"),
+                    prob.panoc_scalars()))
+        prob.close()
+    (x1, z1, r1, s1), (x2, z2, r2, s2) = out
+    assert np.array_equal(x1, x2) and np.array_equal(z1, z2) and np.array_equal(r1, r2)
+    for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "al_z"):
+        assert s1[key] == s2[key], key
+    assert s1["fused"] == 1.0 and s2["fused"] == 0.0
+
+
+def test_alps_matches_oracle_small(bz, ref):
+    """Whole ALPS solve (alps.jl:7-117): resident device outer loop, host outer loop with
+    the device subsolver, and the oracle agree on the solution, multipliers and counts."""
+    n = 3000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    x0b = x0.copy()
+    o = ref.alps(*orc, x0, y0)
+    a = bz.alps(*dev, x0, y0)
+    b = bz.alps(*dev, x0, y0, resident=False)
+    assert np.array_equal(x0, x0b)                      # test_nonconvex_qp.jl:36
+    for r in (a, b):
+        assert r[5] == o[5] == "first_order"
+        assert r[2] == o[2] and r[3] == o[3]
+        assert rel(r[0], o[0]) <= 1e-9
+        assert np.max(np.abs(r[1] - o[1])) <= 1e-8 * max(1.0, np.max(np.abs(o[1])))
+        assert rel(r[9], o[9]) <= 1e-12
+    # first-order fixed point of the box-constrained l1 problem
+    x = a[0]
+    assert np.all(np.abs(x) <= 1 + 1e-6)
+
+
+def test_alps_free_set_closed_form(bz, ref):
+    """cfg 2a (SURVEY §8(c) KAT 5): with D = FreeSet the AL term vanishes and the minimiser is
+    x_i = soft(b_i, lambda)/q_i."""
+    n = 100003
+    d, dev, orc = make_cfg2(bz, ref, n, D="free")
+    out = bz.alps(*dev, np.zeros(n), np.zeros(n), tol=1e-9)
+    xs = np.sign(d["b"]) * np.maximum(np.abs(d["b"]) - d["lam"], 0) / d["q"]
+    assert out[5] == "first_order"
+    assert np.max(np.abs(out[0] - xs)) <= 1e-7
+
+
+def test_mu_must_be_positive(bz, ref):
+    n = 100
+    d, dev, orc = make_cfg2(bz, ref, n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    mu = np.ones(n)
+    mu[17] = 0.0
+    with pytest.raises(ValueError, match="must be positive"):      # auglagfun.jl:92-93
+        prob.set_multipliers(mu, np.zeros(n))
+    prob.close()
+
+
+def test_float32_path(bz, ref):
+    """T = Float32 (cfg 4's eltype): element-wise bit-exact vs the float32 oracle."""
+    n = 40003
+    d, dev, orc = make_cfg2(bz, ref, n, dtype=np.float32)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n).astype(np.float32)
+    mu = (10.0 ** rng.uniform(-2, 0, n)).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    prob = bz.Problem(*dev, n, n, np.float32)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x)
+    g_ref = np.empty(n, np.float32)
+    lx = al.gradient(g_ref, x)
+    assert np.array_equal(g_dev, g_ref)
+    assert abs(vals[0] - float(lx)) <= 2e-4 * max(1.0, abs(float(lx)))
+    z_dev, gz = prob.eval_prox(x, 0.3)
+    z_ref = np.empty(n, np.float32)
+    orc[1].prox(z_ref, x, np.float32(0.3))
+    assert np.array_equal(z_dev, z_ref)
+    prob.close()

@@ -62,7 +62,9 @@ int bz_ctx_create(const bz_ctx_opts* o, bz_ctx** out) {
             c->c.device = o->device; c->c.rank = o->rank; c->c.nranks = o->nranks;
             BZ_HIP(hipSetDevice(o->device));
             BZ_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
-            if (o->nranks > 1) {
+            // nranks == 1 with a comm_id builds a 1-rank communicator: exercises the all-gather
+            // plumbing on a single GPU (tests)
+            if (o->nranks > 1 || o->comm_id) {
                 need(o->comm_id, "comm_id");
                 ncclUniqueId id;
                 std::memcpy(&id, o->comm_id, sizeof(id));
@@ -184,7 +186,7 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y, const 
 }
 
 int bz_profile_enable(bz_problem* p, int32_t on) {
-    return guard([&] { need(p, "problem"); p->s->profile_enable(on != 0); });
+    return guard([&] { need(p, "problem"); p->s->profile_enable((unsigned)on); });
 }
 int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms) {
     return guard([&] { need(p, "problem"); need(launches, "launches"); need(total_ms, "total_ms"); p->s->profile_get(category, launches, total_ms); });

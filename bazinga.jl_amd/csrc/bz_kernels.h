@@ -729,7 +729,7 @@ struct CollectArgs {
     unsigned maxmask;
     int n;
 };
-// one block: fold every source and write the scalars to (host-mapped) `out`
+// one block per source: fold it and write the scalar to (host-mapped) `out`
 __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out);
 
 // multi-GPU: fold the block partials of slots [first, first+cnt) into send[first+i]

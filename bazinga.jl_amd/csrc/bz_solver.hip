@@ -24,12 +24,12 @@ Ctx::~Ctx() {
 }
 
 // ---------------------------------------------------------------------------
+// one block per scalar: fold source blockIdx.x and write it to (host-mapped) out
 __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out) {
     __shared__ double sh[WAVES];
-    for (int i = 0; i < a.n; ++i) {
-        double t = fold_src(a.src[i], (a.maxmask >> i) & 1u, sh);
-        if (threadIdx.x == 0) out[i] = t;
-    }
+    const int i = blockIdx.x;
+    double t = fold_src(a.src[i], (a.maxmask >> i) & 1u, sh);
+    if (threadIdx.x == 0) out[i] = t;
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -43,7 +43,7 @@ k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, doub
 }
 
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
-                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7 };
+                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8 };
 
 template <class T> class Solver final : public SolverBase {
    public:
@@ -219,7 +219,7 @@ template <class T> class Solver final : public SolverBase {
         copy_out(d, D_.p, n);
     }
 
-    void profile_enable(bool on) override { prof_on = on; }
+    void profile_enable(unsigned mask) override { prof_mask = mask; }
     void profile_reset() override {
         drain_prof();
         for (int c = 0; c < BZ_NUM_KERNEL_CATEGORIES; ++c) { prof_ms[c] = 0; prof_n[c] = 0; }
@@ -350,7 +350,7 @@ template <class T> class Solver final : public SolverBase {
 
     // profiling
     struct ProfRec { int cat; hipEvent_t a, b; };
-    bool prof_on = false;
+    unsigned prof_mask = 0;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[BZ_NUM_KERNEL_CATEGORIES] = {0};
@@ -373,6 +373,7 @@ template <class T> class Solver final : public SolverBase {
 
     template <class K, class... A> void launch(int cat, K kernel, int g, A... args) {
         ProfRec r{cat, nullptr, nullptr};
+        const bool prof_on = (prof_mask >> cat) & 1u;
         if (prof_on) { r.a = get_event(); r.b = get_event(); BZ_HIP(hipEventRecord(r.a, ctx->stream)); }
         hipLaunchKernelGGL(kernel, dim3(g), dim3(BLOCK), 0, ctx->stream, args...);
         if (prof_on) {
@@ -403,14 +404,14 @@ template <class T> class Solver final : public SolverBase {
 
     // multi-GPU: fold this rank's block partials of slots [first, first+cnt) and all-gather
     void gather(int first, int cnt, unsigned maxmask) {
-        if (ctx->nranks <= 1) return;
+        if (!ctx->comm) return;
         launch(C_GATHER, k_pack, 1, (const double*)parts_.p, grid, first, cnt, maxmask, send_.p);
         BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
                               ctx->comm, ctx->stream));
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
     }
     ScalarSrc src(int slot) const {
-        if (ctx->nranks <= 1) return ScalarSrc{parts_.p + (size_t)slot * PSTRIDE, grid, 1};
+        if (!ctx->comm) return ScalarSrc{parts_.p + (size_t)slot * PSTRIDE, grid, 1};
         const int f = grp_first[slot], c = grp_cnt[slot];
         return ScalarSrc{recv_.p + (size_t)f * ctx->nranks + (slot - f), ctx->nranks, c};
     }
@@ -423,7 +424,7 @@ template <class T> class Solver final : public SolverBase {
             // partials of slots produced with the y-grid have grid_y entries; identical when c = I
             ++a.n;
         }
-        launch(C_COLLECT, k_collect, 1, a, host_out_dev_);
+        launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
         BZ_HIP(hipStreamSynchronize(ctx->stream));
         return std::vector<double>(host_out_, host_out_ + a.n);
     }
@@ -496,7 +497,7 @@ template <class T> class Solver final : public SolverBase {
             t.src = ScalarSrc{parts_.p, 0, 1}; t.ys = T(1);
             return t;
         }
-        launch(C_TWOLOOP, k_dot<T>, grid, (const T*)S_[order[0]].p, res, T(-1), n, parts_.p, SL_LOOP1 + 0);
+        launch(C_DOT, k_dot<T>, grid, (const T*)S_[order[0]].p, res, T(-1), n, parts_.p, SL_LOOP1 + 0);
         gather(SL_LOOP1 + 0, 1, 0u);
         for (int j = 0; j + 1 < m; ++j) {        // loop 1: d -= alpha_j y_j ; <s_{j+1}, d>
             TailArgs<T> a = t;

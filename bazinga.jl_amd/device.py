@@ -21,9 +21,9 @@ class Context:
         o = L.CtxOpts()
         o.device, o.rank, o.nranks = device, rank, nranks
         self._id = None
-        if nranks > 1:
-            if comm_id is None or len(comm_id) != 128:
-                raise ValueError("nranks > 1 needs the 128-byte id from unique_id() on rank 0")
+        if nranks > 1 and (comm_id is None or len(comm_id) != 128):
+            raise ValueError("nranks > 1 needs the 128-byte id from unique_id() on rank 0")
+        if comm_id is not None:
             self._id = C.create_string_buffer(comm_id, 128)
             o.comm_id = C.cast(self._id, C.c_void_p)
         h = C.c_void_p()
@@ -173,7 +173,9 @@ class Problem:
         return d
 
     def profile_enable(self, on=True):
-        L.check(L.load().bz_profile_enable(self._h, 1 if on else 0))
+        """on: True (all categories), False, or a bitmask over _lib.KERNEL_CATEGORIES."""
+        mask = -1 if on is True else (0 if on is False else int(on))
+        L.check(L.load().bz_profile_enable(self._h, mask))
 
     def profile_reset(self):
         L.check(L.load().bz_profile_reset(self._h))

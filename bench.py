@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — PANOCplus inner iterations/sec on the BASELINE headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md §8(d) cfg 2): l1-regularised diagonal
+quadratic, n = 10^7, fp64, f = sum x(0.5 q x - b), g = 2.5||x||_1 (soft-threshold prox),
+c = Identity, D = Box[-1,1], LBFGS(5), mu = default_penalty_parameter!(x0 = 0) = 0.1,
+y = 0 (outer iteration 1), tol = 0 so the solver never stops; synthetic splitmix64 data.
+
+A "step" is one PANOCplus inner iteration (one Base.iterate(iter, state)).  Inputs and all
+solver state are resident in HBM before the timed region starts.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the SAME n = 10^7 problem
+with x sharded in contiguous blocks over the ranks ("scaling": "strong"); the only data
+exchanged are the reductions' partial scalars (RCCL all-gather of <= 10 doubles per rank).
+
+Output: ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+M_LBFGS = 5
+
+
+def algorithmic_bytes_per_iter(n, w=8, m=M_LBFGS, n_al=2, n_fb=1, p_al=6):
+    """B_iter = w n [(8m+1) + P_AL nAL + 4 nFB + 8]  (cfg 2: 65 passes)."""
+    return w * n * ((8 * m + 1) + p_al * n_al + 4 * n_fb + 8)
+
+
+def cpu_baseline(n, states):
+    """The oracle's plain-C port (oracle/c/bz_oracle.c: single-threaded, one loop per Julia
+    broadcast) timed on this box's host cores on the same workload, bounded sample."""
+    from oracle import c_port
+    import bazinga_jl_amd as bz
+    d = bz.synth.l1_quadratic(n)
+    mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
+    c_port.load()
+    t0 = time.perf_counter()
+    c_port.panoc_run(d["q"], d["b"], mu, y, x0, states, lam=d["lam"], D="box", D_lo=d["lo"], D_hi=d["hi"],
+                     minimum_gamma=float(np.finfo(float).eps))
+    dt = time.perf_counter() - t0
+    return {"value": round((states - 1) / dt, 4), "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"first {states - 1} PANOCplus iterations (plus the initial state) of the same n={n} "
+                      f"workload, oracle/c/bz_oracle.c, single thread, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=float, default=1e7, help="global problem size (default: BASELINE cfg 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-states", type=int, default=13)
+    ap.add_argument("--no-fuse", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import bazinga_jl_amd as bz
+
+    n = int(args.n)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with that many ranks "
+                         f"(WORLD_SIZE={world})")
+    dist = None
+    comm_id = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(bz.Context.unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(idt, 0)
+        comm_id = bytes(idt.cpu().numpy().tobytes())
+    ctx = bz.Context(device=local_rank if world > 1 else 0, rank=rank, nranks=world, comm_id=comm_id)
+
+    lo_i, hi_i = bz.shard_bounds(n, rank, world)
+    nl = hi_i - lo_i
+    d = bz.synth.l1_quadratic(nl, start=lo_i)
+    prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                      bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), nl, nl, np.float64, ctx)
+    prob.set_multipliers(np.full(nl, 0.1), np.zeros(nl))
+    opts = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),
+                        fuse=not args.no_fuse).c_opts()
+    prob.panoc_begin(opts, np.zeros(nl))
+    del d
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        prob.panoc_step()
+    # HIP events (recorded by the library on ITS stream) around every launch of the dominant kernel
+    cat = bz._lib.KERNEL_CATEGORIES.index("k_axpy_dot")
+    prob.profile_reset()
+    prob.profile_enable(1 << cat)
+    st0 = prob.panoc_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prob.panoc_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prob.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st1 = prob.panoc_stats()
+    sc = prob.panoc_scalars()
+    prof = prob.profile()["k_axpy_dot"]
+
+    if rank == 0:
+        its = args.steps / elapsed
+        n_fused = st1.n_fused_iters - st0.n_fused_iters
+        n_al = (st1.n_grad - st0.n_grad) / args.steps
+        n_fb = (st1.n_prox - st0.n_prox) / args.steps
+        m = int(sc["lbfgs_mem"])
+        # dominant kernel: k_axpy_dot = one step of the L-BFGS two-loop (d = +-d + coef*v, then <w,d>).
+        # per iteration at m = 5: 8 launches of 3R+1W and the middle one (v == w) 2R+1W over the
+        # local shard -> algorithmic bytes per launch = (35/9) * 8 * n_local
+        launches_per_it = prof["launches"] / max(1, args.steps)
+        passes = (4.0 * (2 * m - 2) + 3.0) / (2 * m - 1) if m >= 1 else 0.0
+        bytes_per_launch = passes * 8 * nl
+        avg_s = (prof["total_ms"] / 1e3) / max(1, prof["launches"])
+        achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_k_axpy_dot.json")
+        if os.path.exists(pmc) and world == 1 and n == 10_000_000:
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        b_iter = algorithmic_bytes_per_iter(n, n_al=2, n_fb=1)
+        out = {
+            "metric": "PANOC inner iterations/sec, n=10^7 l1-quadratic",
+            "value": round(its, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "cfg2: l1-regularised diagonal quadratic, n=%d fp64, soft-threshold prox_g, "
+                                   "c=Identity, D=Box[-1,1], LBFGS(5), mu=0.1, y=0, tol=0" % n,
+                       "n": n, "n_per_gpu": nl, "lbfgs_memory": M_LBFGS,
+                       "parallelism": "single GPU" if world == 1 else f"x sharded over {world} GPUs, scalar all-gather"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "bz::k_axpy_dot<double>", "launches_per_iteration": round(launches_per_it, 2),
+                         "avg_launch_us": round(avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+            "roofline_iteration": {"algorithmic_bytes_per_iteration": b_iter,
+                                   "achieved": round(b_iter * its / 1e9, 1), "unit": "GB/s",
+                                   "frac": round(b_iter * its / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "SURVEY §8(d) model, 65 passes at m=5, nAL=2, nFB=1"},
+            "solver": {"fused_iterations": int(n_fused), "al_grads_per_it": n_al, "prox_per_it": n_fb,
+                       "lbfgs_mem": m, "gamma": sc["gamma"], "stop_norm": sc["stop_norm"],
+                       "k": int(sc["k"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_states)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    prob.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

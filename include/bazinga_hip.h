@@ -72,7 +72,8 @@ typedef struct {
     int32_t rank;         /* this rank, 0..nranks-1                                  */
     int32_t nranks;       /* 1 = single GPU; >1 = x sharded, scalars all-gathered    */
     int32_t reserved;
-    const void* comm_id;  /* nranks>1: 128-byte id from bz_comm_unique_id on rank 0  */
+    const void* comm_id;  /* nranks>1: 128-byte id from bz_comm_unique_id on rank 0
+                             (nranks==1 + id: 1-rank communicator, for testing)      */
 } bz_ctx_opts;
 
 int  bz_comm_unique_id(void* id128);                 /* fills 128 bytes (RCCL id)     */
@@ -215,11 +216,12 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
                   const void* v, void* d);
 
 /* ---- in-library kernel timing (HIP events on the solver's stream) ----------- */
-/* category: 0 two-loop axpy+dot, 1 fused separable iteration kernel,
+/* category: 0 k_axpy_dot (two-loop step), 1 k_fused_sep (fused separable iteration),
  *           2 AL gradient, 3 forward-backward step, 4 L-BFGS update/stop norm,
- *           5 scalar collect, 6 all-gather                                          */
-#define BZ_NUM_KERNEL_CATEGORIES 8
-int bz_profile_enable(bz_problem* p, int32_t on);
+ *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot).
+ * mask: bit c enables timing of category c (0 = off, -1 = all).                     */
+#define BZ_NUM_KERNEL_CATEGORIES 10
+int bz_profile_enable(bz_problem* p, int32_t mask);
 int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms);
 int bz_profile_reset(bz_problem* p);
 

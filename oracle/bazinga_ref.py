@@ -51,6 +51,48 @@ from dataclasses import dataclass, field
 import numpy as np
 
 # ---------------------------------------------------------------------------
+# Reductions over the decision / constraint vectors go through REDUCER so that a test
+# can run the SAME restatement on a shard of x and fold the partial scalars across
+# ranks (tests/test_sharded_cpu.py, world_size 2 over gloo): the multi-GPU design
+# shards x and exchanges scalars only.
+# ---------------------------------------------------------------------------
+class LocalReducer:
+    """Single-process reductions (numpy pairwise sum / BLAS dot)."""
+
+    def sum(self, v):
+        return np.sum(v)
+
+    def dot(self, a, b):
+        return np.dot(a, b)
+
+    def max(self, v):
+        return np.max(v) if v.size else v.dtype.type(0)
+
+    def any(self, m):
+        return bool(np.any(m))
+
+
+REDUCER = LocalReducer()
+
+
+def set_reducer(r):
+    global REDUCER
+    REDUCER = r if r is not None else LocalReducer()
+
+
+def _sum(v):
+    return REDUCER.sum(v)
+
+
+def _dot(a, b):
+    return REDUCER.dot(a, b)
+
+
+def _max(v):
+    return REDUCER.max(v)
+
+
+# ---------------------------------------------------------------------------
 # oracle protocol (README.md:17-20, src/Bazinga.jl:11-16)
 #   f(x) -> value ; f.gradient(out, x) -> value          [gradient!]
 #   g.prox(z, x, gamma) -> g(z)                            [prox!]
@@ -148,10 +190,10 @@ class NormL1:
             gl = T(gamma) * T(self.lam)
             # y[i] = x[i] + (x[i] <= -gl ? gl : (x[i] >= gl ? -gl : -x[i]))
             y[...] = x + np.where(x <= -gl, gl, np.where(x >= gl, -gl, -x))
-            return T(self.lam) * np.sum(np.abs(y))
+            return T(self.lam) * _sum(np.abs(y))
         gl = T(gamma) * np.asarray(self.lam, dtype=x.dtype)
         y[...] = x + np.where(x <= -gl, gl, np.where(x >= gl, -gl, -x))
-        return np.sum(np.asarray(self.lam, dtype=x.dtype) * np.abs(y))
+        return _sum(np.asarray(self.lam, dtype=x.dtype) * np.abs(y))
 
 
 class NormL1Nonneg:
@@ -170,7 +212,7 @@ class NormL1Nonneg:
         gl = T(gamma) * T(self.lam)
         m = x >= gl
         y[...] = np.where(m, x - gl, T(0))
-        return T(self.lam) * np.sum(y)
+        return T(self.lam) * _sum(y)
 
 
 class NormL1Box:
@@ -191,7 +233,7 @@ class NormL1Box:
         T = x.dtype.type
         gl = T(gamma) * T(self.lam)
         y[...] = np.maximum(T(0), np.minimum(x - gl, self.u.astype(x.dtype, copy=False)))
-        return T(self.lam) * np.sum(y)
+        return T(self.lam) * _sum(y)
 
 
 class IndBox:
@@ -239,13 +281,13 @@ class DiagQuadratic:
     def __call__(self, x):
         T = x.dtype.type
         qx = self.q * x
-        return np.sum(x * (T(0.5) * qx - self.b))
+        return _sum(x * (T(0.5) * qx - self.b))
 
     def gradient(self, dfx, x):
         T = x.dtype.type
         qx = self.q * x
         dfx[...] = qx - self.b
-        return np.sum(x * (T(0.5) * qx - self.b))
+        return _sum(x * (T(0.5) * qx - self.b))
 
 
 class Stencil5ptQuadratic:
@@ -418,13 +460,13 @@ class AugLagFun:
     """auglagfun.jl:11-101.  L(x) = f(x) + 1/(2mu) dist_D^2(c(x)+mu y) - mu/2 ||y||^2"""
 
     def __init__(self, f, c, D, mu, y, x):
-        if np.any(mu <= 0):                                   # :33-34
+        if REDUCER.any(mu <= 0):                              # :33-34
             raise ValueError("parameters `mu` must be positive")
         T = x.dtype.type
         self.f, self.c, self.D = f, c, D
         self.mu, self.y = mu, y                               # aliases, as in Julia
         self.muy = mu * y                                     # :36
-        self.musqy = T(0.5) * np.sum(self.muy * y)            # :37
+        self.musqy = T(0.5) * _sum(self.muy * y)              # :37
         self.cx = np.empty_like(y)
         self.s = np.empty_like(y)
         self.yupd = np.empty_like(y)
@@ -441,7 +483,7 @@ class AugLagFun:
         np.add(self.cx, self.muy, out=self.yupd)
         self.D.proj(self.s, self.yupd)
         self.yupd -= self.s
-        lx = T(0.5) * np.sum(self.yupd ** 2 / self.mu)
+        lx = T(0.5) * _sum(self.yupd ** 2 / self.mu)
         self.yupd /= self.mu
         self.fx = self.f(x)
         lx += self.fx
@@ -455,7 +497,7 @@ class AugLagFun:
         np.add(self.cx, self.muy, out=self.yupd)              # cx + mu.*y
         self.D.proj(self.s, self.yupd)                        # s
         self.yupd -= self.s                                   # cx + mu.*y - s
-        lx = T(0.5) * np.sum(self.yupd ** 2 / self.mu)
+        lx = T(0.5) * _sum(self.yupd ** 2 / self.mu)
         self.yupd /= self.mu                                  # yupd
         self.fx = self.f.gradient(self.dfx, x)                # fx, dfx
         lx += self.fx
@@ -466,13 +508,13 @@ class AugLagFun:
 
 
 def AugLagUpdate(al: AugLagFun, mu, y):                       # :91-101
-    if np.any(mu <= 0):
+    if REDUCER.any(mu <= 0):
         raise ValueError("parameters `mu` must be positive")
     T = y.dtype.type
     al.mu[...] = mu
     al.y[...] = y
     al.muy[...] = al.mu * al.y
-    al.musqy = T(0.5) * np.sum(al.muy * al.y)
+    al.musqy = T(0.5) * _sum(al.muy * al.y)
     return None
 
 
@@ -504,7 +546,7 @@ class LBFGSOperator:
         self.H = T(1)
 
     def update(self, s, y):
-        ys = np.dot(s, y)
+        ys = _dot(s, y)
         if ys > 0:
             self.curridx += 1
             if self.curridx > self.M:
@@ -515,7 +557,7 @@ class LBFGSOperator:
             self.ys_M[self.curridx - 1] = ys
             self.s_M[self.curridx - 1][...] = s
             self.y_M[self.curridx - 1][...] = y
-            yty = np.dot(y, y)
+            yty = _dot(y, y)
             self.H = ys / yty
         return ys
 
@@ -527,7 +569,7 @@ class LBFGSOperator:
         d[...] = v
         idx = self.curridx
         for _ in range(self.currmem):                       # loop1
-            a = np.dot(self.s_M[idx - 1], d) / self.ys_M[idx - 1]
+            a = _dot(self.s_M[idx - 1], d) / self.ys_M[idx - 1]
             self.alphas[idx - 1] = a
             d -= a * self.y_M[idx - 1]
             idx -= 1
@@ -538,19 +580,19 @@ class LBFGSOperator:
             idx += 1
             if idx > self.M:
                 idx = 1
-            beta = np.dot(self.y_M[idx - 1], d) / self.ys_M[idx - 1]
+            beta = _dot(self.y_M[idx - 1], d) / self.ys_M[idx - 1]
             d += (self.alphas[idx - 1] - beta) * self.s_M[idx - 1]
         return d
 
 
 def _norm(v):
-    return np.sqrt(np.dot(v, v))
+    return np.sqrt(_dot(v, v))
 
 
 def f_model(f_x, grad_f_x, res, L):
     """f_x - <grad, res> + (L/2) ||res||^2"""
     nr = _norm(res)
-    return f_x - np.dot(grad_f_x, res) + (L / 2) * (nr * nr)
+    return f_x - _dot(grad_f_x, res) + (L / 2) * (nr * nr)
 
 
 def lower_bound_smoothness_constant(f, x, grad_f_x):
@@ -722,7 +764,7 @@ class PANOCplusIteration:
         return st
 
     def stop_norm(self, st):
-        return np.max(np.abs(st.res / st.gamma - st.grad_f_x + st.grad_f_z))
+        return _max(np.abs(st.res / st.gamma - st.grad_f_x + st.grad_f_z))
 
 
 class PANOCplus:
@@ -825,7 +867,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         y -= s                                                # :80
         y /= mu                                               # :81
         norm_res_prim_old = norm_res_prim
-        norm_res_prim = np.max(np.abs(cx - s)) if cx.size else T(0)   # :84
+        norm_res_prim = _max(np.abs(cx - s))                  # :84
 
         solved = (inner_tol <= tol_dual and sub_solved) and (norm_res_prim <= tol_prim)
         tired = tot_it >= maxit

@@ -133,7 +133,7 @@ def test_panoc_iterates_match_oracle(bz, ref, n, D):
         x0 = np.zeros(n)
         prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 30)
         for k, ex, ez, g_d, g_r, sn_d, sn_r, fused in rows:
-            assert g_d == g_r, f"gamma differs at k={k}"
+            assert abs(g_d - g_r) <= 1e-13 * g_r, f"gamma differs at k={k}"
             assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k}: {ex} {ez}"
             assert abs(sn_d - sn_r) <= 1e-9 * max(1.0, sn_r)
         assert sum(r[-1] for r in rows) >= 20      # the fused fast path actually served the iterations
@@ -232,3 +232,50 @@ def test_float32_path(bz, ref):
     orc[1].prox(z_ref, x, np.float32(0.3))
     assert np.array_equal(z_dev, z_ref)
     prob.close()
+
+
+def test_allgather_plumbing_single_rank(bz, ref):
+    """The multi-GPU scalar path (k_pack -> RCCL all-gather -> fold over ranks) on a 1-rank
+    communicator must reproduce the single-GPU iterates bit for bit."""
+    n = 30011
+    d, dev, orc = make_cfg2(bz, ref, n)
+    rng = np.random.default_rng(2)
+    mu = np.full(n, 0.1)
+    y = rng.standard_normal(n)
+    res = []
+    for with_comm in (False, True):
+        ctx = bz.Context(device=0, rank=0, nranks=1, comm_id=bz.Context.unique_id() if with_comm else None)
+        prob = bz.Problem(*dev, n, n, np.float64, ctx)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n))
+        for _ in range(12):
+            prob.panoc_step()
+        res.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars()))
+        prob.close()
+        ctx.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2]["stop_norm"] == res[1][2]["stop_norm"] and res[0][2]["gamma"] == res[1][2]["gamma"]
+
+
+def test_full_size_properties(bz, ref):
+    """BASELINE size n = 10^7 (too big for the numpy oracle to iterate): size-independent
+    properties.  (1) D = FreeSet closed form x_i = soft(b_i, lambda)/q_i;  (2) with D = Box the
+    returned point is a fixed point of the forward-backward map of the final AL subproblem and
+    satisfies the box to tol_prim; (3) x0 is not mutated."""
+    n = 10_000_000
+    d = bz.synth.l1_quadratic(n)
+    f, g, c = bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction()
+    x0 = np.zeros(n)
+    out = bz.alps(f, g, c, bz.FreeSet(), x0, np.zeros(n), tol=1e-8)
+    xs = np.sign(d["b"]) * np.maximum(np.abs(d["b"]) - d["lam"], 0) / d["q"]
+    assert out[5] == "first_order"
+    assert np.max(np.abs(out[0] - xs)) <= 1e-6
+    out = bz.alps(f, g, c, bz.ClosedSet(bz.IndBox(-1.0, 1.0)), x0, np.zeros(n))
+    x, y, mu = out[0], out[1], out[9]
+    assert out[5] == "first_order" and not np.any(x0)
+    assert np.max(np.abs(x - np.clip(x, -1, 1))) <= 1e-6            # primal feasibility (alps.jl:84,87)
+    # KKT of  min f + g  s.t. x in [-1,1]:  0 in q x - b + y + lam sign(x)
+    r = d["q"] * x - d["b"] + y
+    viol = np.where(x > 1e-9, np.abs(r + d["lam"]), np.where(x < -1e-9, np.abs(r - d["lam"]),
+                    np.maximum(np.abs(r) - d["lam"], 0)))
+    assert np.max(viol) <= 1e-4

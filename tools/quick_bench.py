@@ -1,0 +1,35 @@
+"""Quick single-GPU timing of the cfg-2 PANOCplus inner iteration (development aid)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bazinga_jl_amd as bz
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+fuse = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+d = bz.synth.l1_quadratic(n)
+prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                  bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), n, n, np.float64)
+print(prob.ctx.info())
+mu = np.full(n, 0.1); y = np.zeros(n)
+prob.set_multipliers(mu, y)
+opts = bz.PANOCplus(tol=0.0, maxit=10**9, minimum_gamma=np.finfo(float).eps, fuse=bool(fuse)).c_opts()
+prob.panoc_begin(opts, np.zeros(n))
+for _ in range(20):
+    prob.panoc_step()
+t0 = time.perf_counter()
+for _ in range(steps):
+    prob.panoc_step()
+t1 = time.perf_counter()
+sc = prob.panoc_scalars(); st = prob.panoc_stats()
+its = steps / (t1 - t0)
+print(f"n={n} fuse={fuse}: {its:.1f} it/s  ({1e6/its:.1f} us/it)  model 520n B/it -> {520*n*its/1e12:.3f} TB/s = {520*n*its/8e12:.3f} of 8 TB/s")
+print("scalars", sc)
+print("stats fused", st.n_fused_iters, "grad", st.n_grad, "prox", st.n_prox, "bt", st.n_backtracks, "halv", st.n_gamma_halvings, "skips", st.n_lbfgs_skips)
+prob.profile_enable(True); prob.profile_reset()
+for _ in range(50):
+    prob.panoc_step()
+p = prob.profile()
+for k, v in p.items():
+    if v["launches"]:
+        print(f"  {k:20s} launches/it={v['launches']/50:5.1f}  avg={1e3*v['total_ms']/v['launches']:8.2f} us  per-it={1e3*v['total_ms']/50:8.1f} us")

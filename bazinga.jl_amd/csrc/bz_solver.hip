@@ -8,6 +8,8 @@
 // provenance of the restatement.
 #include "bz_solver.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -374,12 +376,14 @@ template <class T> class Solver final : public SolverBase {
     template <class K, class... A> void launch(int cat, K kernel, int g, A... args) {
         ProfRec r{cat, nullptr, nullptr};
         const bool prof_on = (prof_mask >> cat) & 1u;
-        if (prof_on) { r.a = get_event(); r.b = get_event(); BZ_HIP(hipEventRecord(r.a, ctx->stream)); }
-        hipLaunchKernelGGL(kernel, dim3(g), dim3(BLOCK), 0, ctx->stream, args...);
         if (prof_on) {
-            BZ_HIP(hipEventRecord(r.b, ctx->stream));
+            // start/stop events bound to the dispatch itself: kernel time without the launch gap
+            r.a = get_event(); r.b = get_event();
+            hipExtLaunchKernelGGL(kernel, dim3(g), dim3(BLOCK), 0, ctx->stream, r.a, r.b, 0, args...);
             prof_recs.push_back(r);
             if (prof_recs.size() > 8192) drain_prof();
+        } else {
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(BLOCK), 0, ctx->stream, args...);
         }
         BZ_HIP(hipGetLastError());
     }

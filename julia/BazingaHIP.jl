@@ -1,0 +1,138 @@
+# BazingaHIP.jl — the reference-side binding a Bazinga.jl maintainer would add.
+#
+# NOT RUNNABLE IN THE BUILD CONTAINER (no `julia` there); written against include/bazinga_hip.h and kept
+# in sync with the ctypes binding bazinga.jl_amd/_lib.py, whose struct layouts ARE tested against the
+# header (tests/test_abi.py).
+#
+# Usage — nothing else in user code changes:
+#     using Bazinga, BazingaHIP
+#     out = Bazinga.alps(f, g, c, D, x0, y0; subsolver = BazingaHIP.PANOCplus)      # seam alps.jl:24,64-66
+# or, with device-resident outer loop:
+#     out = BazingaHIP.alps(f, g, c, D, x0, y0)
+module BazingaHIP
+
+using Bazinga
+import ProximalOperators
+
+const lib = get(ENV, "BAZINGA_HIP_LIB", "libbazinga_hip.so")
+
+# ---- mirrors of the C structs (include/bazinga_hip.h) ----------------------------------------
+struct CtxOpts
+    device::Int32; rank::Int32; nranks::Int32; reserved::Int32; comm_id::Ptr{Cvoid}
+end
+Base.@kwdef mutable struct ProblemDesc
+    dtype::Int32 = 0; f_kind::Int32 = 0; g_kind::Int32 = 0; c_kind::Int32 = 0; D_kind::Int32 = 0
+    data_on_device::Int32 = 0
+    n::Int64 = 0; ny::Int64 = 0
+    f_q::Ptr{Cvoid} = C_NULL; f_b::Ptr{Cvoid} = C_NULL; f_grid_nx::Int64 = 0; f_grid_ny::Int64 = 0
+    g_lambda::Float64 = 0; g_u::Ptr{Cvoid} = C_NULL; g_lo::Float64 = 0; g_hi::Float64 = 0
+    g_lo_vec::Ptr{Cvoid} = C_NULL; g_hi_vec::Ptr{Cvoid} = C_NULL
+    c_A::Ptr{Cvoid} = C_NULL; c_b::Ptr{Cvoid} = C_NULL
+    D_lo::Float64 = 0; D_hi::Float64 = 0; D_lo_vec::Ptr{Cvoid} = C_NULL; D_hi_vec::Ptr{Cvoid} = C_NULL
+end
+Base.@kwdef mutable struct PanocOpts
+    tol::Float64 = 1e-8; maxit::Int64 = 1000; freq::Int32 = 10; verbose::Int32 = 0
+    minimum_gamma::Float64 = 1e-7; alpha::Float64 = 0.95; beta::Float64 = 0.5
+    max_backtracks::Int32 = 20; lbfgs_memory::Int32 = 5; fuse::Int32 = 1; reserved::Int32 = 0
+end
+Base.@kwdef mutable struct PanocStats
+    iters::Int64 = 0; f_z::Float64 = 0; g_z::Float64 = 0; al_z::Float64 = 0; gamma::Float64 = 0
+    tau::Float64 = 0; stop_norm::Float64 = 0; n_grad::Int64 = 0; n_prox::Int64 = 0
+    n_backtracks::Int64 = 0; n_gamma_halvings::Int64 = 0; n_fused_iters::Int64 = 0
+    n_lbfgs_skips::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; reserved::Int32 = 0
+end
+
+function check(rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:bz_last_error, lib), Cstring, ()))
+    error(msg)                       # same ErrorException the reference throws (auglagfun.jl:33-34)
+end
+
+const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
+function context()
+    if _ctx[] == C_NULL
+        o = Ref(CtxOpts(0, 0, 1, 0, C_NULL))
+        check(ccall((:bz_ctx_create, lib), Cint, (Ref{CtxOpts}, Ref{Ptr{Cvoid}}), o, _ctx))
+    end
+    _ctx[]
+end
+
+# ---- structured oracle types this build adds (SURVEY §8(b)) ------------------------------------
+struct DiagQuadratic{T} <: Bazinga.ProximableFunction
+    q::Vector{T}; b::Vector{T}            # f(x) = sum x_i (0.5 q_i x_i - b_i)
+end
+
+# ---- lowering: pattern-match the oracle structs -> bz_problem_desc ----------------------------
+dtype_code(::Type{Float64}) = Int32(0)
+dtype_code(::Type{Float32}) = Int32(1)
+
+lower_f!(d, f::Bazinga.Zero) = (d.f_kind = 0)
+lower_f!(d, f::ProximalOperators.Zero) = (d.f_kind = 0)
+lower_f!(d, f::DiagQuadratic) = (d.f_kind = 1; d.f_q = pointer(f.q); d.f_b = pointer(f.b))
+lower_f!(d, f) = error("BazingaHIP: f of type $(typeof(f)) is not lowered to the device")
+
+lower_g!(d, g::Bazinga.Zero) = (d.g_kind = 0)
+lower_g!(d, g::ProximalOperators.Zero) = (d.g_kind = 0)
+lower_g!(d, g::ProximalOperators.IndFree) = (d.g_kind = 0)
+lower_g!(d, g::ProximalOperators.NormL1{<:Real}) = (d.g_kind = 1; d.g_lambda = g.lambda)
+lower_g!(d, g::Bazinga.NormL1Nonneg) = (d.g_kind = 2; d.g_lambda = g.lambda)
+lower_g!(d, g::Bazinga.NormL1Box) = (d.g_kind = 3; d.g_lambda = g.lambda; d.g_u = pointer(g.u))
+lower_g!(d, g::ProximalOperators.IndBox{<:Real,<:Real}) = (d.g_kind = 4; d.g_lo = g.lb; d.g_hi = g.ub)
+lower_g!(d, g) = error("BazingaHIP: g of type $(typeof(g)) is not lowered to the device")
+
+# c: any SmoothFunction whose eval!/jtprod! are the identity (e.g. test/definitions/identityFunction.jl)
+abstract type IdentityLike <: Bazinga.SmoothFunction end
+lower_c!(d, c::IdentityLike) = (d.c_kind = 0)
+lower_c!(d, c) = error("BazingaHIP: c of type $(typeof(c)) is not lowered to the device")
+
+lower_D!(d, D::Bazinga.ZeroSet) = (d.D_kind = 0)
+lower_D!(d, D::Bazinga.FreeSet) = (d.D_kind = 1)
+lower_D!(d, D::Bazinga.IndicatorSet{<:ProximalOperators.IndBox{<:Real,<:Real}}) =
+    (d.D_kind = 2; d.D_lo = D.f.lb; d.D_hi = D.f.ub)
+lower_D!(d, D) = error("BazingaHIP: D of type $(typeof(D)) is not lowered to the device")
+
+mutable struct Problem
+    h::Ptr{Cvoid}
+    keep::Any
+    function Problem(f, g, c, D, n, ny, ::Type{T}) where {T}
+        d = ProblemDesc(dtype = dtype_code(T), n = n, ny = ny)
+        lower_f!(d, f); lower_g!(d, g); lower_c!(d, c); lower_D!(d, D)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve f g c D check(ccall((:bz_problem_create, lib), Cint,
+            (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), context(), Ref(d), h))
+        p = new(h[], (f, g, c, D))
+        finalizer(p -> ccall((:bz_problem_destroy, lib), Cvoid, (Ptr{Cvoid},), p.h), p)
+    end
+end
+
+# ---- the subsolver seam: drop-in for ProximalAlgorithms.PANOCplus -----------------------------
+struct PANOCplusHIP
+    opts::PanocOpts
+end
+"""`PANOCplus(; directions=LBFGS(5), maxit, tol, verbose, freq, minimum_gamma, ...)` — same keywords
+as ProximalAlgorithms.PANOCplus as the reference configures it (demo/rosenbrock.jl:109-115)."""
+function PANOCplus(; directions = nothing, maxit = 1000, tol = 1e-8, verbose = false, freq = 10,
+                   minimum_gamma = 1e-7, alpha = 0.95, beta = 0.5, max_backtracks = 20, kwargs...)
+    M = directions === nothing ? 5 : directions.memory
+    PANOCplusHIP(PanocOpts(tol = tol, maxit = min(maxit, typemax(Int64)), freq = min(freq, typemax(Int32)),
+                           verbose = verbose, minimum_gamma = minimum_gamma, alpha = alpha, beta = beta,
+                           max_backtracks = max_backtracks, lbfgs_memory = M))
+end
+
+const _problems = IdDict{Any,Problem}()
+
+"`solver(f = alFun, g = gFun, x0 = x) -> (sol, it)`   (alps.jl:66)"
+function (s::PANOCplusHIP)(; f::Bazinga.AugLagFun, g::Bazinga.NonsmoothCostFun, x0::AbstractVector{T}) where {T}
+    p = get!(() -> Problem(f.f, g.g, f.c, f.D, length(x0), length(f.y), T), _problems, f)
+    mu = convert(Vector{T}, f.mu); y = convert(Vector{T}, f.y)
+    check(ccall((:bz_problem_set_multipliers, lib), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), p.h, mu, y))
+    x = similar(x0); st = Ref(PanocStats())
+    check(ccall((:bz_panoc_solve, lib), Cint, (Ptr{Cvoid}, Ref{PanocOpts}, Ptr{T}, Ptr{T}, Ref{PanocStats}),
+                p.h, Ref(s.opts), x0, x, st))
+    f.fx = T(st[].f_z)          # side channels alps reads back (alps.jl:68)
+    g.gz = T(st[].g_z)
+    g.gamma = st[].gamma
+    return x, Int(st[].iters)
+end
+
+end # module

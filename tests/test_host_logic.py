@@ -1,0 +1,117 @@
+"""Host-side logic that needs no GPU: oracle lowering, argument errors, sharding plan,
+synthetic-data generator, safeguards."""
+import numpy as np
+import pytest
+
+
+def test_splitmix64_known_answers(bz):
+    """splitmix64 reference outputs for seed 1234567 (Vigna's published test vector)."""
+    s = bz.synth
+    x = np.uint64(1234567)
+    outs = []
+    with np.errstate(over="ignore"):
+        for _ in range(3):
+            outs.append(int(s.splitmix64(np.array([x], dtype=np.uint64))[0]))
+            x = x + np.uint64(0x9E3779B97F4A7C15)
+    assert outs == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+
+
+def test_synth_is_shard_consistent(bz):
+    full = bz.synth.l1_quadratic(1000)
+    a, b = bz.synth.l1_quadratic(600, start=0), bz.synth.l1_quadratic(400, start=600)
+    assert np.array_equal(full["q"], np.concatenate([a["q"], b["q"]]))
+    assert np.array_equal(full["b"], np.concatenate([a["b"], b["b"]]))
+    assert full["q"].min() >= 0.1 and full["q"].max() <= 10.0 and np.abs(full["b"]).max() <= 10.0
+
+
+@pytest.mark.parametrize("n,nranks", [(10 ** 7, 8), (10 ** 7, 3), (1000, 8), (5, 2), (10 ** 8, 8)])
+def test_shard_bounds_partition(bz, n, nranks):
+    prev = 0
+    for r in range(nranks):
+        lo, hi = bz.shard_bounds(n, r, nranks)
+        assert lo == prev and lo <= hi <= n
+        if hi < n:
+            assert hi % 256 == 0           # 16-byte aligned vector accesses on every shard
+        prev = hi
+    assert prev == n
+
+
+def test_lowering_kinds(bz):
+    from bazinga_jl_amd.oracles import lower
+    L = bz._lib
+    n = 6
+    q, b = np.arange(1.0, 7.0), np.ones(n)
+    d, keep = lower(bz.DiagQuadratic(q, b), bz.NormL1(2.5), bz.IdentityFunction(),
+                    bz.ClosedSet(bz.IndBox(-1.0, 1.0)), n, n, np.float64)
+    assert (d.dtype, d.f_kind, d.g_kind, d.c_kind, d.D_kind) == (L.BZ_F64, L.BZ_F_DIAG_QUADRATIC, L.BZ_G_NORM_L1,
+                                                                 L.BZ_C_IDENTITY, L.BZ_D_BOX)
+    assert d.g_lambda == 2.5 and d.D_lo == -1.0 and d.D_hi == 1.0 and d.n == n and d.ny == n
+    d, _ = lower(bz.Zero(), bz.IndFree(), bz.IdentityFunction(), bz.ZeroSet(), n, n, np.float32)
+    assert (d.dtype, d.f_kind, d.g_kind, d.D_kind) == (L.BZ_F32, L.BZ_F_ZERO, L.BZ_G_ZERO, L.BZ_D_ZERO)
+    lo = -np.ones(n)
+    d, keep = lower(bz.Zero(), bz.IndBox(lo, 2.0), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float64)
+    assert d.g_kind == L.BZ_G_IND_BOX and d.g_lo_vec and not d.g_hi_vec and d.g_hi == 2.0
+
+
+def test_unsupported_oracles_raise(bz):
+    from bazinga_jl_amd.oracles import lower
+
+    class Rosenbrock:     # arbitrary closures cannot run on the device
+        pass
+    n = 4
+    with pytest.raises(bz.UnsupportedOracle):
+        lower(Rosenbrock(), bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float64)
+    with pytest.raises(bz.UnsupportedOracle):
+        lower(bz.Zero(), Rosenbrock(), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float64)
+    with pytest.raises(bz.UnsupportedOracle):
+        lower(bz.Zero(), bz.Zero(), Rosenbrock(), bz.FreeSet(), n, n, np.float64)
+    with pytest.raises(bz.UnsupportedOracle):
+        lower(bz.Zero(), bz.Zero(), bz.IdentityFunction(), Rosenbrock(), n, n, np.float64)
+    with pytest.raises(bz.UnsupportedOracle):
+        lower(bz.Zero(), bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float16)
+    with pytest.raises(ValueError):
+        lower(bz.Zero(), bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), n, n + 1, np.float64)
+
+
+def test_constructor_errors_mirror_reference(bz):
+    with pytest.raises(ValueError):         # normL1Nonneg.jl:15-16
+        bz.NormL1Nonneg(-1.0)
+    with pytest.raises(ValueError):         # normL1Box.jl:18-23
+        bz.NormL1Box(1.0, u=np.array([1.0, -1.0]))
+    with pytest.raises(ValueError):
+        bz.NormL1Box(-1.0, u=np.array([1.0]))
+    mu, y, x = np.array([1.0, 0.0]), np.zeros(2), np.zeros(2)
+    with pytest.raises(ValueError, match="must be positive"):     # auglagfun.jl:33-34
+        bz.AugLagFun(bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), mu, y, x)
+    al = bz.AugLagFun(bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), np.ones(2), y, x)
+    with pytest.raises(ValueError, match="must be positive"):     # auglagfun.jl:92-93
+        bz.AugLagUpdate(al, mu, y)
+
+
+def test_safeguards_match_oracle(bz, ref):
+    rng = np.random.default_rng(0)
+    for dt in (np.float64, np.float32):
+        cx, s = rng.standard_normal(50).astype(dt) * 30, rng.standard_normal(50).astype(dt)
+        for objx in (-3.0, 0.5, 1e5):
+            a, b = np.empty(50, dt), np.empty(50, dt)
+            bz.default_penalty_parameter(a, cx, s, objx)
+            ref.default_penalty_parameter(b, cx, s, objx)
+            assert np.array_equal(a, b) and a.min() >= 1e-8 and a.max() <= 1e8
+    y1 = np.array([1e30, -1e30, 3.0])
+    y2 = y1.copy()
+    bz.default_dual_safeguard(y1)
+    ref.default_dual_safeguard(y2)
+    assert np.array_equal(y1, y2) and np.array_equal(y1, [1e20, -1e20, 3.0])
+
+
+def test_auglag_update_scalars(bz, ref):
+    rng = np.random.default_rng(1)
+    n = 33
+    mu, y, x = rng.uniform(0.1, 1, n), rng.standard_normal(n), np.zeros(n)
+    a = bz.AugLagFun(bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), mu.copy(), y.copy(), x)
+    b = ref.AugLagFun(ref.Zero(), ref.IdentityFunction(), ref.FreeSet(), mu.copy(), y.copy(), x)
+    assert np.array_equal(a.muy, b.muy) and a.musqy == b.musqy
+    mu2, y2 = mu * 0.5, y + 1
+    bz.AugLagUpdate(a, mu2, y2)
+    ref.AugLagUpdate(b, mu2, y2)
+    assert np.array_equal(a.muy, b.muy) and a.musqy == b.musqy

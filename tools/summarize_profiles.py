@@ -1,0 +1,68 @@
+"""Turn rocprofv3 outputs under gpurun_out/ into the small summaries committed under profiles/.
+
+HBM traffic per launch follows MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in
+SEPARATE --pmc passes (TCC slots), both are in KiB, and on gfx950 FETCH_SIZE reports exactly half
+of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled:
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(k_muy is the in-run calibration: it reads exactly two n-vectors and writes one.)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counter_avgs(d, name):
+    files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def short(k):
+    k = k.replace("void ", "")
+    return k.split("(")[0]
+
+
+def main(tag="r01"):
+    go = os.path.join(ROOT, "gpurun_out")
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    stats = glob.glob(os.path.join(go, "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats_bench_n1e7.csv"), "w") as fh:
+            fh.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline\n")
+            fh.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+            for r in rows:
+                fh.write(",".join(['"%s"' % short(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+    fetch = counter_avgs(os.path.join(go, "prof_fetch"), "FETCH_SIZE")
+    write = counter_avgs(os.path.join(go, "prof_write"), "WRITE_SIZE")
+    summary = {}
+    for k in fetch:
+        f, nf = fetch[k]
+        w, nw = write.get(k, (0.0, 0))
+        summary[short(k)] = {"FETCH_SIZE_KiB_avg": round(f, 1), "WRITE_SIZE_KiB_avg": round(w, 1), "launches_fetch_pass": nf,
+                             "launches_write_pass": nw, "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    with open(os.path.join(out_dir, f"{tag}_pmc_hbm_traffic_n1e7.json"), "w") as fh:
+        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 10 --warmup 5 "
+                              "--no-cpu-baseline (two separate passes)",
+                   "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
+                   "n": 10_000_000, "kernels": summary}, fh, indent=1)
+    ax = summary.get("bz::k_axpy_dot<double>")
+    if ax:
+        with open(os.path.join(out_dir, "pmc_k_axpy_dot.json"), "w") as fh:
+            json.dump({"kernel": "bz::k_axpy_dot<double>", "n": 10_000_000, "hbm_bytes_per_launch": ax["hbm_bytes_per_launch"],
+                       "source": f"profiles/{tag}_pmc_hbm_traffic_n1e7.json"}, fh)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])

@@ -371,6 +371,63 @@ k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, in
 }
 
 // ---------------------------------------------------------------------------
+// K10 + K1: AL gradient with the 5-point-stencil quadratic f (cfg 3), c = Identity.
+//   f(x) = 0.5 x'A_h x - b'x on an nx-by-ny grid (row-major, index = i*ny + j),
+//   A_h = (4,-1,-1,-1,-1), homogeneous Dirichlet halo.  Per element (same order as the oracle):
+//     Ax = ((((4 x_c - x_w) - x_e) - x_n) - x_s) ; dfx = Ax - b ; fterm = x_c (0.5 Ax - b)
+//   Each lane owns one 16-B pack of a row (ny % pack == 0, so packs never straddle rows);
+//   north/south packs are the same columns of rows i-1/i+1, west/east are one scalar each.
+//   The three reads of a row (as centre, north, south) hit L2/Infinity Cache: HBM sees x once.
+//   slots: +0 sum f terms, +1 sum t^2/mu.   f_only: skip the AL terms (alps.jl:39, f(x) alone).
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_algrad_stencil(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, int f_only,
+                 T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
+    constexpr int N = PackN<T>::N;
+    double acc[2] = {0.0, 0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        const int64_t i = i0 / ny, j0 = i0 - i * ny;
+        Pack<T> xc = ld(x, i0, cnt);
+        Pack<T> xn = (i > 0) ? ld(x, i0 - ny, cnt) : splat(T(0));
+        Pack<T> xs = (i + 1 < nx) ? ld(x, i0 + ny, cnt) : splat(T(0));
+        const T west = (j0 > 0) ? x[i0 - 1] : T(0);
+        const T east = (j0 + N < ny) ? x[i0 + N] : T(0);
+        Pack<T> pb = ld(P.b, i0, cnt);
+        ElemLoads<T> L;
+        if (!f_only) load_params(P, i0, cnt, L, false, true, false);
+        Pack<T> pg;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const T c = xc.v[e];
+            const T w = (e == 0) ? west : xc.v[e > 0 ? e - 1 : 0];
+            const T ee = (e == N - 1) ? east : xc.v[e < N - 1 ? e + 1 : N - 1];
+            T Ax = T(4) * c;
+            Ax = Ax - w;
+            Ax = Ax - ee;
+            Ax = Ax - xn.v[e];
+            Ax = Ax - xs.v[e];
+            const T dfx = Ax - pb.v[e];
+            const T fterm = c * (T(0.5) * Ax - pb.v[e]);
+            T g = dfx, pterm = T(0);
+            if (!f_only) {
+                T t = c + L.muy.v[e];
+                T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e]);
+                t = t - sv;
+                pterm = (t * t) / L.mu.v[e];
+                T yupd = t / L.mu.v[e];
+                g = dfx + yupd;
+            }
+            pg.v[e] = g;
+            if (e < cnt) { acc[0] += (double)fterm; acc[1] += (double)pterm; }
+        }
+        if (grad) st(grad, i0, cnt, pg);
+    }
+    block_reduce_store<2>(acc, 0u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
 // K3: forward-backward step  y = x - gamma*g ; z = prox(y) ; res = x - z
 //   slots: +0 sum g terms (multiply by lambda on the host), +1 <g,res>, +2 ||res||^2
 //   g == nullptr: pure prox of x (used for prox_{eps g}(x0), alps.jl:38)

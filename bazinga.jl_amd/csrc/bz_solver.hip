@@ -55,8 +55,16 @@ template <class T> class Solver final : public SolverBase {
             throw Error(BZ_ERR_ARG, "c = Identity requires ny == n");
         if (d.c_kind != BZ_C_IDENTITY)
             throw Error(BZ_ERR_UNSUPPORTED, "constraint kind not lowered to the device");
-        if (d.f_kind != BZ_F_ZERO && d.f_kind != BZ_F_DIAG_QUADRATIC)
+        if (d.f_kind != BZ_F_ZERO && d.f_kind != BZ_F_DIAG_QUADRATIC && d.f_kind != BZ_F_STENCIL5)
             throw Error(BZ_ERR_UNSUPPORTED, "smooth-cost kind not lowered to the device");
+        if (d.f_kind == BZ_F_STENCIL5) {
+            if (d.f_grid_nx <= 0 || d.f_grid_ny <= 0 || d.f_grid_nx * d.f_grid_ny != n)
+                throw Error(BZ_ERR_ARG, "Stencil5pt: grid nx*ny must equal n");
+            if (d.f_grid_ny % PackN<T>::N != 0)
+                throw Error(BZ_ERR_ARG, "Stencil5pt: grid columns must be a multiple of 16 bytes");
+            if (ctx->nranks > 1)
+                throw Error(BZ_ERR_UNSUPPORTED, "Stencil5pt is not sharded (needs a halo exchange)");
+        }
         if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_IND_BOX)
             throw Error(BZ_ERR_ARG, "unknown g kind");
         if (d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_BOX) throw Error(BZ_ERR_ARG, "unknown D kind");
@@ -78,6 +86,11 @@ template <class T> class Solver final : public SolverBase {
             if (!d.f_q || !d.f_b) throw Error(BZ_ERR_ARG, "DiagQuadratic needs q and b");
             upload(q_, d.f_q, n); upload(b_, d.f_b, n);
             P.q = q_.p; P.b = b_.p;
+        }
+        if (d.f_kind == BZ_F_STENCIL5) {
+            if (!d.f_b) throw Error(BZ_ERR_ARG, "Stencil5pt needs b");
+            upload(b_, d.f_b, n);
+            P.b = b_.p;
         }
         P.g_lambda = (T)d.g_lambda;
         if (d.g_kind == BZ_G_NORM_L1_BOX) {
@@ -245,8 +258,7 @@ template <class T> class Solver final : public SolverBase {
                parts_.p, (int)SL_GSUM);
         gather(SL_GSUM, 3, 0u);
         // objx = f(x) + gFun.gz                                        alps.jl:39
-        launch(C_MISC, k_fvalue_elem<T>, grid, (const T*)x, P, n, parts_.p, (int)SL_AUX);
-        gather(SL_AUX, 1, 0u);
+        fvalue(x, SL_AUX);
         auto v0 = collect({SL_GSUM, SL_AUX}, 0u);
         T gz0 = g_value(v0[0]);
         T objx = T(v0[1]) + gz0;
@@ -449,8 +461,21 @@ template <class T> class Solver final : public SolverBase {
 
     // gradient!(dlx, al, x) on the device; partials -> slot0 (f terms), slot0+1 (t^2/mu)
     void algrad(const T* x, T* grad, int slot0) {
-        launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0);
+        if (desc.f_kind == BZ_F_STENCIL5)
+            launch(C_ALGRAD, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 0,
+                   grad, n, parts_.p, slot0);
+        else
+            launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0);
         gather(slot0, 2, 0u);
+    }
+    // f(x) alone (alps.jl:39): partial sums -> slot0
+    void fvalue(const T* x, int slot0) {
+        if (desc.f_kind == BZ_F_STENCIL5)
+            launch(C_MISC, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 1,
+                   (T*)nullptr, n, parts_.p, slot0);
+        else
+            launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0);
+        gather(slot0, 1, 0u);
     }
 
     // AugLagUpdate!(al, mu, y)  (auglagfun.jl:91-101) on the device copies mu_, ymul_

@@ -46,6 +46,18 @@ class DiagQuadratic(ProximableFunction):
             raise ValueError("q and b must be vectors of equal length")
 
 
+class Stencil5ptQuadratic(ProximableFunction):
+    """f(x) = 0.5 x'A_h x - b'x on an nx-by-ny grid (row-major), A_h the 5-point Laplacian
+    (4,-1,-1,-1,-1) with homogeneous Dirichlet halo — the structured `Quadratic` of BASELINE
+    config 3; 1-D analogue in the reference: demo/obstacle.jl:97-112."""
+
+    def __init__(self, nx, ny, b):
+        self.nx, self.ny = int(nx), int(ny)
+        self.b = np.ascontiguousarray(b)
+        if self.b.shape != (self.nx * self.ny,):
+            raise ValueError("b must have length nx*ny")
+
+
 # ------------------------------------------------------------------------- g
 class IndFree(ProximableFunction):
     """ProximalOperators.IndFree (test_nonconvex_qp.jl:39)."""
@@ -148,6 +160,10 @@ def lower(f, g, c, D, n, ny, dtype):
     elif isinstance(f, DiagQuadratic):
         d.f_kind = L.BZ_F_DIAG_QUADRATIC
         d.f_q = ptr(_vec(f.q, dtype, n, "q"))
+        d.f_b = ptr(_vec(f.b, dtype, n, "b"))
+    elif isinstance(f, Stencil5ptQuadratic):
+        d.f_kind = L.BZ_F_STENCIL5
+        d.f_grid_nx, d.f_grid_ny = f.nx, f.ny
         d.f_b = ptr(_vec(f.b, dtype, n, "b"))
     else:
         raise UnsupportedOracle(f"f of type {type(f).__name__} is not lowered to the device")

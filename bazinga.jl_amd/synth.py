@@ -40,8 +40,9 @@ def l1_quadratic(n: int, start: int = 0, dtype=np.float64):
     return {"q": q, "b": b, "lam": 2.5, "lo": -1.0, "hi": 1.0}
 
 
-def obstacle_grid(nx: int = 2048, ny: int | None = None, dtype=np.float64):
-    """cfg 3: 5-pt Laplacian QP on an nx-by-ny grid, b = h^2, obstacle
+def obstacle_grid(nx: int = 2048, ny: int | None = None, dtype=np.float64, load: float = 1.0):
+    """cfg 3: 5-pt Laplacian QP on an nx-by-ny grid, b = load*h^2 (SURVEY: load = +1; load = -1
+    pushes the membrane onto the obstacle so the constraint is active), obstacle
     psi_ij = 0.05 - 0.5((i h - .5)^2 + (j h - .5)^2), h = 1/(nx+1), i,j = 1..n;
     D = Box[psi, +inf), x0 = max(0, psi)."""
     ny = nx if ny is None else ny
@@ -49,7 +50,7 @@ def obstacle_grid(nx: int = 2048, ny: int | None = None, dtype=np.float64):
     i = (np.arange(1, nx + 1) * h - 0.5) ** 2
     j = (np.arange(1, ny + 1) * (1.0 / (ny + 1)) - 0.5) ** 2
     psi = (0.05 - 0.5 * (i[:, None] + j[None, :])).reshape(-1).astype(dtype)
-    b = np.full(nx * ny, h * h, dtype=dtype)
+    b = np.full(nx * ny, load * h * h, dtype=dtype)
     return {"nx": nx, "ny": ny, "b": b, "psi": psi, "x0": np.maximum(0, psi).astype(dtype)}
 
 

@@ -279,3 +279,73 @@ def test_full_size_properties(bz, ref):
     viol = np.where(x > 1e-9, np.abs(r + d["lam"]), np.where(x < -1e-9, np.abs(r - d["lam"]),
                     np.maximum(np.abs(r) - d["lam"], 0)))
     assert np.max(viol) <= 1e-4
+
+
+# ------------------------------------------------------------------ cfg 3: 5-pt stencil QP, box D
+def make_cfg3(bz, ref, nx, ny, load=1.0):
+    d = bz.synth.obstacle_grid(nx, ny, load=load)
+    n = nx * ny
+    dev = (bz.Stencil5ptQuadratic(nx, ny, d["b"]), bz.Zero(), bz.IdentityFunction(),
+           bz.ClosedSet(bz.IndBox(d["psi"], np.inf)))
+    orc = (ref.Stencil5ptQuadratic(nx, ny, d["b"]), ref.Zero(), ref.IdentityFunction(),
+           ref.ClosedSet(ref.IndBox(d["psi"], np.inf)))
+    return d, n, dev, orc
+
+
+@pytest.mark.parametrize("shape", [(1, 2), (2, 2), (3, 8), (17, 34), (64, 128), (2048, 2048)])
+def test_stencil_al_gradient_bit_exact(bz, ref, shape):
+    """K10+K1: gradient!(dlx, al, x) with the 5-point-stencil f — bit-exact up to the FULL BASELINE
+    size 2048^2 (one numpy evaluation is cheap), every boundary case included."""
+    nx, ny = shape
+    d, n, dev, orc = make_cfg3(bz, ref, nx, ny)
+    rng = np.random.default_rng(nx * 7 + ny)
+    x = rng.standard_normal(n)
+    mu = 10.0 ** rng.uniform(-3, 0, n)
+    y = rng.standard_normal(n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x)
+    g_ref = np.empty(n)
+    lx = al.gradient(g_ref, x)
+    assert np.array_equal(g_dev, g_ref)
+    assert abs(vals[0] - lx) <= 1e-12 * max(1.0, abs(lx))
+    assert abs(vals[1] - al.fx) <= 1e-12 * max(1.0, abs(al.fx))
+    prob.close()
+
+
+@pytest.mark.parametrize("shape,iters", [((16, 32), 40), ((200, 128), 25), ((2048, 2048), 8)])
+def test_stencil_panoc_iterates_match_oracle(bz, ref, shape, iters):
+    nx, ny = shape
+    d, n, dev, orc = make_cfg3(bz, ref, nx, ny)
+    mu = np.full(n, 0.1)
+    y = np.zeros(n)
+    prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, d["x0"].copy(), iters,
+                                minimum_gamma=float(np.finfo(float).eps))
+    for k, ex, ez, g_d, g_r, sn_d, sn_r, fused in rows:
+        assert abs(g_d - g_r) <= 1e-13 * g_r
+        assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k}: {ex} {ez}"
+        assert abs(sn_d - sn_r) <= 1e-9 * max(1e-3, sn_r)
+    prob.close()
+
+
+def test_stencil_alps_small_obstacle(bz, ref):
+    """Whole ALPS on a small obstacle problem: same counts and solution as the oracle; the solution
+    satisfies the obstacle KKT system  A x - b + y = 0, x >= psi, y <= 0, y (x - psi) = 0."""
+    nx, ny = 24, 32
+    d, n, dev, orc = make_cfg3(bz, ref, nx, ny, load=-1.0)     # load pushes onto the obstacle
+    sub = lambda **kw: bz.PANOCplus(maxit=100000, minimum_gamma=float(np.finfo(float).eps), **kw)
+    subr = lambda **kw: ref.PANOCplus(maxit=100000, minimum_gamma=float(np.finfo(float).eps), **kw)
+    a = bz.alps(*dev, d["x0"], np.zeros(n), subsolver=sub, resident=True)
+    o = ref.alps(*orc, d["x0"], np.zeros(n), subsolver=subr)
+    assert a[5] == o[5] == "first_order"
+    assert a[2] == o[2]
+    assert abs(a[3] - o[3]) <= max(3, 0.02 * o[3])       # inner counts may differ by a late branch flip
+    assert np.max(np.abs(a[0] - o[0])) <= 1e-6
+    x, y = a[0], a[1]
+    g = np.empty(n)
+    orc[0].gradient(g, x)
+    assert np.max(np.abs(g + y)) <= 1e-4
+    assert np.min(x - d["psi"]) >= -1e-5 and np.max(y) <= 1e-6
+    assert np.max(np.abs(y * (x - d["psi"]))) <= 1e-5
+    assert np.sum(x - d["psi"] <= 1e-6) > 10                 # the obstacle is really active

@@ -18,9 +18,9 @@ BZ_F_ZERO, BZ_F_DIAG_QUADRATIC, BZ_F_STENCIL5 = 0, 1, 2
 BZ_G_ZERO, BZ_G_NORM_L1, BZ_G_NORM_L1_NONNEG, BZ_G_NORM_L1_BOX, BZ_G_IND_BOX = 0, 1, 2, 3, 4
 BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
-NUM_KERNEL_CATEGORIES = 10
+NUM_KERNEL_CATEGORIES = 12
 KERNEL_CATEGORIES = ("k_axpy_dot", "k_fused_sep", "al_gradient", "fb_step",
-                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot")
+                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv")
 
 
 class CtxOpts(C.Structure):

@@ -428,6 +428,139 @@ k_algrad_stencil(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t n
 }
 
 // ---------------------------------------------------------------------------
+// K9: dense constraint map c(x) = A x - b (demo/basispursuit.jl:38-49), A[ny][n] row-major.
+// Both products are bound by the bytes of A (2 flop per 4 B); x / v stay in L2.
+// ---------------------------------------------------------------------------
+// cx = A p - b : one block per row (grid-strided), lanes along the contiguous columns.
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_gemv_n(const T* __restrict__ A, const T* __restrict__ p, const T* __restrict__ b,
+         T* __restrict__ cx, int64_t ny, int64_t n) {
+    constexpr int N = PackN<T>::N;
+    __shared__ double sh[WAVES];
+    const int64_t npk = n / N;              // host guarantees n % N == 0
+    for (int64_t r = blockIdx.x; r < ny; r += gridDim.x) {
+        const T* row = A + r * n;
+        T a0 = T(0), a1 = T(0);
+        int64_t c = threadIdx.x;
+        for (; c + BLOCK < npk; c += 2 * BLOCK) {
+            Pack<T> ra = *reinterpret_cast<const Pack<T>*>(row + c * N);
+            Pack<T> rb = *reinterpret_cast<const Pack<T>*>(row + (c + BLOCK) * N);
+            Pack<T> pa = *reinterpret_cast<const Pack<T>*>(p + c * N);
+            Pack<T> pb = *reinterpret_cast<const Pack<T>*>(p + (c + BLOCK) * N);
+#pragma unroll
+            for (int e = 0; e < N; ++e) { a0 += ra.v[e] * pa.v[e]; a1 += rb.v[e] * pb.v[e]; }
+        }
+        for (; c < npk; c += BLOCK) {
+            Pack<T> ra = *reinterpret_cast<const Pack<T>*>(row + c * N);
+            Pack<T> pa = *reinterpret_cast<const Pack<T>*>(p + c * N);
+#pragma unroll
+            for (int e = 0; e < N; ++e) a0 += ra.v[e] * pa.v[e];
+        }
+        double v = wave_sum((double)a0 + (double)a1);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            T dot = (T)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+            cx[r] = dot - b[r];
+        }
+        __syncthreads();
+    }
+}
+
+// the ny-vector part of gradient!(dlx, al, x) (auglagfun.jl:74-78):
+//   t = cx + muy ; s = proj_D(t) ; t -= s ; slot +0 sum t^2/mu ; yupd = t/mu
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_yupd(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ yupd, int64_t ny,
+       double* __restrict__ parts, int slot0) {
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, ny) {
+        BZ_CHUNK_VARS(T, ny)
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, false, true, false);
+        Pack<T> pc = ld(cx, i0, cnt), py;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T t = pc.v[e] + L.muy.v[e];
+            T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e]);
+            t = t - sv;
+            T pterm = (t * t) / L.mu.v[e];
+            py.v[e] = t / L.mu.v[e];
+            if (e < cnt) acc[0] += (double)pterm;
+        }
+        st(yupd, i0, cnt, py);
+    }
+    block_reduce_store<1>(acc, 0u, parts, slot0);
+}
+
+// jtv partials: part[rc][j] = sum_{i in row chunk rc} A[i][j] v[i].  blockIdx.x = column block
+// (BLOCK packs), blockIdx.y = row chunk.  Each wave-load is 1 KiB contiguous of one row.
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_gemv_t(const T* __restrict__ A, const T* __restrict__ v, T* __restrict__ part, int64_t ny,
+         int64_t n, int rows_per_chunk) {
+    constexpr int N = PackN<T>::N;
+    const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;     // pack index along the row
+    if (c * N >= n) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = (r0 + rows_per_chunk < ny) ? r0 + rows_per_chunk : ny;
+    Pack<T> a0 = splat(T(0)), a1 = splat(T(0));
+    const T* col = A + c * N;
+    int64_t r = r0;
+    for (; r + 1 < r1; r += 2) {
+        Pack<T> ra = *reinterpret_cast<const Pack<T>*>(col + r * n);
+        Pack<T> rb = *reinterpret_cast<const Pack<T>*>(col + (r + 1) * n);
+        const T va = v[r], vb = v[r + 1];
+#pragma unroll
+        for (int e = 0; e < N; ++e) { a0.v[e] += ra.v[e] * va; a1.v[e] += rb.v[e] * vb; }
+    }
+    if (r < r1) {
+        Pack<T> ra = *reinterpret_cast<const Pack<T>*>(col + r * n);
+        const T va = v[r];
+#pragma unroll
+        for (int e = 0; e < N; ++e) a0.v[e] += ra.v[e] * va;
+    }
+    Pack<T> o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) o.v[e] = a0.v[e] + a1.v[e];
+    *reinterpret_cast<Pack<T>*>(part + (int64_t)blockIdx.y * n + c * N) = o;
+}
+
+// dlx = dfx + jtv with jtv = sum over row chunks (fixed order) ; f element-wise (Zero|DiagQuadratic)
+//   slot +0: sum f terms
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_gemv_t_finish(const T* __restrict__ part, int nchunks, const T* __restrict__ x, ElemParams<T> P,
+                T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> j = ld(part, i0, cnt);
+        for (int k = 1; k < nchunks; ++k) {
+            Pack<T> q = ld(part + (int64_t)k * n, i0, cnt);
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) j.v[e] = j.v[e] + q.v[e];
+        }
+        Pack<T> px = ld(x, i0, cnt), pq = splat(T(0)), pb = splat(T(0)), pg;
+        if (P.f_kind == BZ_F_DIAG_QUADRATIC) { pq = ld(P.q, i0, cnt); pb = ld(P.b, i0, cnt); }
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T dfx = T(0), fterm = T(0);
+            if (P.f_kind == BZ_F_DIAG_QUADRATIC) {
+                T qx = pq.v[e] * px.v[e];
+                dfx = qx - pb.v[e];
+                fterm = px.v[e] * (T(0.5) * qx - pb.v[e]);
+            }
+            pg.v[e] = dfx + j.v[e];
+            if (e < cnt) acc[0] += (double)fterm;
+        }
+        if (grad) st(grad, i0, cnt, pg);
+    }
+    block_reduce_store<1>(acc, 0u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
 // K3: forward-backward step  y = x - gamma*g ; z = prox(y) ; res = x - z
 //   slots: +0 sum g terms (multiply by lambda on the host), +1 <g,res>, +2 ||res||^2
 //   g == nullptr: pure prox of x (used for prox_{eps g}(x0), alps.jl:38)

@@ -45,7 +45,7 @@ k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, doub
 }
 
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
-                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8 };
+                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9 };
 
 template <class T> class Solver final : public SolverBase {
    public:
@@ -53,8 +53,15 @@ template <class T> class Solver final : public SolverBase {
         if (n <= 0 || ny < 0) throw Error(BZ_ERR_ARG, "n must be positive");
         if (d.c_kind == BZ_C_IDENTITY && ny != n)
             throw Error(BZ_ERR_ARG, "c = Identity requires ny == n");
-        if (d.c_kind != BZ_C_IDENTITY)
+        if (d.c_kind != BZ_C_IDENTITY && d.c_kind != BZ_C_DENSE_AFFINE)
             throw Error(BZ_ERR_UNSUPPORTED, "constraint kind not lowered to the device");
+        if (d.c_kind == BZ_C_DENSE_AFFINE) {
+            if (ny <= 0 || !d.c_A || !d.c_b) throw Error(BZ_ERR_ARG, "DenseAffine needs A[ny][n] and b[ny]");
+            if (n % PackN<T>::N != 0) throw Error(BZ_ERR_ARG, "DenseAffine: n must be a multiple of 16 bytes");
+            if (d.f_kind == BZ_F_STENCIL5) throw Error(BZ_ERR_UNSUPPORTED, "Stencil5pt f with a dense c");
+            if (ctx->nranks > 1)
+                throw Error(BZ_ERR_UNSUPPORTED, "DenseAffine is not sharded (needs an n-vector all-reduce)");
+        }
         if (d.f_kind != BZ_F_ZERO && d.f_kind != BZ_F_DIAG_QUADRATIC && d.f_kind != BZ_F_STENCIL5)
             throw Error(BZ_ERR_UNSUPPORTED, "smooth-cost kind not lowered to the device");
         if (d.f_kind == BZ_F_STENCIL5) {
@@ -79,6 +86,18 @@ template <class T> class Solver final : public SolverBase {
         const int64_t nychunks = (ny + PackN<T>::N - 1) / PackN<T>::N;
         grid_y = (int)std::min<int64_t>(grid, std::max<int64_t>(1, (nychunks + BLOCK - 1) / BLOCK));
         if (d.c_kind == BZ_C_IDENTITY) grid_y = grid;
+        if (d.c_kind == BZ_C_DENSE_AFFINE) {
+            A_.alloc((size_t)ny * n);
+            BZ_HIP(hipMemcpyAsync(A_.p, d.c_A, (size_t)ny * n * sizeof(T), hipMemcpyDefault, ctx->stream));
+            BZ_HIP(hipStreamSynchronize(ctx->stream));
+            upload(cb_, d.c_b, ny);
+            CX_.alloc(ny); YU_.alloc(ny);
+            const int64_t colblocks = (n / PackN<T>::N + BLOCK - 1) / BLOCK;
+            int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ny, (2048 + colblocks - 1) / colblocks));
+            rows_per_chunk = (int)((ny + chunks - 1) / chunks);
+            nrowchunks = (int)((ny + rows_per_chunk - 1) / rows_per_chunk);
+            GT_.alloc((size_t)nrowchunks * n);
+        }
 
         std::memset(&P, 0, sizeof(P));
         P.f_kind = d.f_kind; P.g_kind = d.g_kind; P.D_kind = d.D_kind;
@@ -120,7 +139,8 @@ template <class T> class Solver final : public SolverBase {
         recv_.alloc((size_t)SL_COUNT * std::max(1, ctx->nranks));
         BZ_HIP(hipHostMalloc((void**)&host_out_, sizeof(double) * MAX_COLLECT, hipHostMallocMapped));
         BZ_HIP(hipHostGetDevicePointer((void**)&host_out_dev_, host_out_, 0));
-        for (int s = 0; s < SL_COUNT; ++s) { grp_first[s] = s; grp_cnt[s] = 1; }
+        for (int s = 0; s < SL_COUNT; ++s) { grp_first[s] = s; grp_cnt[s] = 1; slot_n[s] = grid; }
+        slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
         BZ_HIP(hipStreamSynchronize(ctx->stream));
     }
 
@@ -264,7 +284,10 @@ template <class T> class Solver final : public SolverBase {
         T objx = T(v0[1]) + gz0;
         // eval!(cx,c,x); proj!(s,D,cx); default_penalty_parameter!     alps.jl:40-42
         const double denom = std::max(1.0, (double)objx);
-        launch(C_MISC, k_penalty_init<T>, grid_y, (const T*)x /* cx = x */, P, denom, sproj_.p, mu_.p, ny);
+        const bool dense_c = desc.c_kind == BZ_C_DENSE_AFFINE;
+        if (dense_c) eval_c(x);
+        launch(C_MISC, k_penalty_init<T>, grid_y, dense_c ? (const T*)CX_.p : (const T*)x /* cx = x */, P, denom,
+               sproj_.p, mu_.p, ny);
         copy_in(ymul_.p, y0, ny);                                    // y .= y0
         double norm_res_prim = 0, norm_res_prim_old = 0;
         bool have_old = false, have_res = false;
@@ -291,8 +314,9 @@ template <class T> class Solver final : public SolverBase {
             tot_inner += sub_it;
             const bool sub_solved = sub_it < ao.subsolver_maxit;     // alps.jl:70
             // dual update + primal residual                          alps.jl:72-84
-            launch(C_MISC, k_dual_update<T>, grid_y, (const T*)x, P, ymul_.p, sproj_.p, ny, parts_.p,
-                   (int)SL_OUTER);
+            if (dense_c) eval_c(x);                                  // eval!(cx, c, x)  alps.jl:72
+            launch(C_MISC, k_dual_update<T>, grid_y, dense_c ? (const T*)CX_.p : (const T*)x, P, ymul_.p, sproj_.p,
+                   ny, parts_.p, (int)SL_OUTER);
             gather(SL_OUTER, 1, 1u);
             auto r = collect({SL_OUTER}, 1u);
             norm_res_prim_old = norm_res_prim; have_old = have_res;
@@ -336,11 +360,14 @@ template <class T> class Solver final : public SolverBase {
     ElemParams<T> P;
     DBuf<T> q_, b_, gu_, glo_, ghi_, dlo_, dhi_, mu_, muy_, ymul_, sproj_;
     DBuf<T> X_[3], RES_[2], Z_[2], GX_, GZ_, D_, TMP_;
+    DBuf<T> A_, cb_, CX_, YU_, GT_;          // DenseAffine c: A[ny][n], b, c(x), yupd, A'v row-chunk partials
+    int rows_per_chunk = 1, nrowchunks = 1;
     std::vector<DBuf<T>> S_, Y_;
     DBuf<double> parts_, alphas_, send_, recv_;
     double* host_out_ = nullptr;
     double* host_out_dev_ = nullptr;
     int grp_first[SL_COUNT], grp_cnt[SL_COUNT];
+    int slot_n[SL_COUNT];                    // number of valid block partials per slot
 
     // solver state (host scalars)
     bz_panoc_opts opt{};
@@ -400,6 +427,18 @@ template <class T> class Solver final : public SolverBase {
         BZ_HIP(hipGetLastError());
     }
 
+    template <class K, class... A> void launch2d(int cat, K kernel, int gx, int gy, A... args) {
+        ProfRec r{cat, nullptr, nullptr};
+        if ((prof_mask >> cat) & 1u) {
+            r.a = get_event(); r.b = get_event();
+            hipExtLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, ctx->stream, r.a, r.b, 0, args...);
+            prof_recs.push_back(r);
+        } else {
+            hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, ctx->stream, args...);
+        }
+        BZ_HIP(hipGetLastError());
+    }
+
     void upload(DBuf<T>& dst, const void* src, int64_t cnt) {
         dst.alloc(cnt);
         copy_in(dst.p, src, cnt);
@@ -427,7 +466,7 @@ template <class T> class Solver final : public SolverBase {
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
     }
     ScalarSrc src(int slot) const {
-        if (!ctx->comm) return ScalarSrc{parts_.p + (size_t)slot * PSTRIDE, grid, 1};
+        if (!ctx->comm) return ScalarSrc{parts_.p + (size_t)slot * PSTRIDE, slot_n[slot], 1};
         const int f = grp_first[slot], c = grp_cnt[slot];
         return ScalarSrc{recv_.p + (size_t)f * ctx->nranks + (slot - f), ctx->nranks, c};
     }
@@ -437,7 +476,6 @@ template <class T> class Solver final : public SolverBase {
         a.n = 0; a.maxmask = maxmask;
         for (int s : slots) {
             a.src[a.n] = src(s);
-            // partials of slots produced with the y-grid have grid_y entries; identical when c = I
             ++a.n;
         }
         launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
@@ -460,7 +498,22 @@ template <class T> class Solver final : public SolverBase {
     }
 
     // gradient!(dlx, al, x) on the device; partials -> slot0 (f terms), slot0+1 (t^2/mu)
+    // eval!(cx, c, x) for the dense constraint
+    void eval_c(const T* x) {
+        launch(C_GEMV, k_gemv_n<T>, (int)std::min<int64_t>(ny, 65535), (const T*)A_.p, x, (const T*)cb_.p, CX_.p, ny, n);
+    }
     void algrad(const T* x, T* grad, int slot0) {
+        if (desc.c_kind == BZ_C_DENSE_AFFINE) {
+            eval_c(x);                                                        // cx = A x - b
+            launch(C_MISC, k_yupd<T>, grid_y, (const T*)CX_.p, P, YU_.p, ny, parts_.p, slot0 + 1);
+            slot_n[slot0] = grid; slot_n[slot0 + 1] = grid_y;
+            const int colblocks = (int)((n / PackN<T>::N + BLOCK - 1) / BLOCK);
+            launch2d(C_GEMV, k_gemv_t<T>, colblocks, nrowchunks, (const T*)A_.p, (const T*)YU_.p, GT_.p, ny, n,
+                     rows_per_chunk);                                         // jtv = A' yupd (row-chunk partials)
+            launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, x, P, grad, n, parts_.p, slot0);
+            gather(slot0, 2, 0u);
+            return;
+        }
         if (desc.f_kind == BZ_F_STENCIL5)
             launch(C_ALGRAD, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 0,
                    grad, n, parts_.p, slot0);
@@ -587,6 +640,7 @@ template <class T> class Solver final : public SolverBase {
         algrad(TMP_.p, GZ_.p, SL_FZ); ++n_grad;
         launch(C_MISC, k_diff_ss2<T>, grid, (const T*)GZ_.p, (const T*)GX_.p, (const T*)TMP_.p, (const T*)x, n,
                parts_.p, (int)SL_AUX);
+        slot_n[SL_AUX] = slot_n[SL_AUX + 1] = grid;
         gather(SL_AUX, 2, 0u);
         {
             auto v = collect({SL_FXD, SL_PXD, SL_AUX, SL_AUX + 1}, 0u);

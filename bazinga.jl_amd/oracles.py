@@ -108,6 +108,17 @@ class IdentityFunction(SmoothFunction):
     """test/definitions/identityFunction.jl:3-13"""
 
 
+class DenseAffine(SmoothFunction):
+    """c(x) = A x - b with a dense row-major A[ny][n]: `ConstraintBasisPursuit`
+    (demo/basispursuit.jl:38-49); eval! = A*x - b, jtprod! = A'*v."""
+
+    def __init__(self, A, b):
+        self.A = np.ascontiguousarray(A)
+        self.b = np.ascontiguousarray(b)
+        if self.A.ndim != 2 or self.b.shape != (self.A.shape[0],):
+            raise ValueError("A must be ny-by-n and b of length ny")
+
+
 # ------------------------------------------------------------------------- D
 class ZeroSet(ClosedSetBase):
     """src/projections/zeroSet.jl:8-20"""
@@ -194,6 +205,13 @@ def lower(f, g, c, D, n, ny, dtype):
         d.c_kind = L.BZ_C_IDENTITY
         if ny != n:
             raise ValueError("IdentityFunction requires length(y0) == length(x0)")
+    elif isinstance(c, DenseAffine):
+        d.c_kind = L.BZ_C_DENSE_AFFINE
+        if c.A.shape != (ny, n):
+            raise ValueError(f"A must be {ny}-by-{n}")
+        A = np.ascontiguousarray(c.A, dtype=dtype)
+        d.c_A = ptr(A)
+        d.c_b = ptr(_vec(c.b, dtype, ny, "b"))
     else:
         raise UnsupportedOracle(f"c of type {type(c).__name__} is not lowered to the device")
     # D

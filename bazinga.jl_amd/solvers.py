@@ -191,7 +191,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     probe.set_multipliers(np.ones_like(y0), np.zeros_like(y0))
     _, vals = probe.eval_al_gradient(x)
     objx = T(vals[1]) + gFun.gz                                 # :39
-    cx[...] = x                                                 # :40 (c = Identity is the only lowered c here)
+    cx[...] = _eval_c_host(c, x)                                # :40
     s[...] = _proj_host(D, cx)                                  # :41
     default_penalty_parameter(mu, cx, s, objx)                  # :42
     y[...] = y0                                                 # :43
@@ -218,7 +218,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         objx = alFun.fx + gFun.gz                               # :68
         tot_inner_it += sub_it
         sub_solved = sub_it < subsolver_maxit                   # :70
-        cx[...] = x                                             # :72
+        cx[...] = _eval_c_host(c, x)                            # :72
         np.add(cx, alFun.muy, out=y)                            # :74
         s[...] = _proj_host(D, y)                               # :75
         y -= s                                                  # :80
@@ -238,6 +238,16 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     elapsed_time = time.time() - start_time
     status = "first_order" if solved else ("max_iter" if tired else ("exception" if broken else "unknown"))
     return x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu
+
+
+def _eval_c_host(c, x):
+    """eval!(cx, c, x) for the host outer loop's O(ny) bookkeeping (outside the hot path)."""
+    from .oracles import DenseAffine, IdentityFunction
+    if isinstance(c, IdentityFunction):
+        return x
+    if isinstance(c, DenseAffine):
+        return (c.A @ x - c.b).astype(x.dtype, copy=False)
+    raise UnsupportedOracle(f"c of type {type(c).__name__} is not lowered")
 
 
 def _proj_host(D, v):

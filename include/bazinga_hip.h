@@ -218,9 +218,10 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
 /* ---- in-library kernel timing (HIP events on the solver's stream) ----------- */
 /* category: 0 k_axpy_dot (two-loop step), 1 k_fused_sep (fused separable iteration),
  *           2 AL gradient, 3 forward-backward step, 4 L-BFGS update/stop norm,
- *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot).
+ *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot),
+ *           9 dense GEMV kernels.
  * mask: bit c enables timing of category c (0 = off, -1 = all).                     */
-#define BZ_NUM_KERNEL_CATEGORIES 10
+#define BZ_NUM_KERNEL_CATEGORIES 12
 int bz_profile_enable(bz_problem* p, int32_t mask);
 int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms);
 int bz_profile_reset(bz_problem* p);

@@ -349,3 +349,92 @@ def test_stencil_alps_small_obstacle(bz, ref):
     assert np.min(x - d["psi"]) >= -1e-5 and np.max(y) <= 1e-6
     assert np.max(np.abs(y * (x - d["psi"]))) <= 1e-5
     assert np.sum(x - d["psi"] <= 1e-6) > 10                 # the obstacle is really active
+
+
+# ------------------------------------------------------------------ cfg 4: basis pursuit, dense A
+def make_cfg4(bz, ref, ny, n, dtype, density=0.05):
+    d = bz.synth.basis_pursuit(ny, n, dtype=dtype, density=density)
+    dev = (bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(d["A"], d["b"]), bz.ZeroSet())
+    orc = (ref.Zero(), ref.NormL1(1.0), ref.DenseAffine(d["A"], d["b"]), ref.ZeroSet())
+    return d, dev, orc
+
+
+@pytest.mark.parametrize("shape", [(20, 100), (3, 8), (64, 512), (257, 1028)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_al_gradient(bz, ref, shape, dtype):
+    """K9+K1: gradient!(dlx, al, x) with c(x) = A x - b (demo/basispursuit.jl:38-49), D = ZeroSet.
+    GEMV sums are order-dependent: tolerance 1e-12 (fp64) / 2e-5 (fp32) relative to ||grad||_inf."""
+    ny, n = shape
+    d, dev, orc = make_cfg4(bz, ref, ny, n, dtype)
+    rng = np.random.default_rng(ny + n)
+    x = rng.standard_normal(n).astype(dtype)
+    mu = (10.0 ** rng.uniform(-2, 0, ny)).astype(dtype)
+    y = rng.standard_normal(ny).astype(dtype)
+    prob = bz.Problem(*dev, n, ny, dtype)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x)
+    g_ref = np.empty(n, dtype)
+    lx = float(al.gradient(g_ref, x))
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert np.max(np.abs(g_dev.astype(np.float64) - g_ref)) <= tol * np.max(np.abs(g_ref))
+    assert abs(vals[0] - lx) <= tol * max(1.0, abs(lx))
+    prob.close()
+
+
+def test_dense_panoc_and_alps_fp64(bz, ref):
+    """The reference's own basis-pursuit demo shape (demo/basispursuit.jl:55-66: 20x100) in fp64:
+    iterates follow the oracle, ALPS returns a feasible l1 solution."""
+    ny, n = 20, 100
+    d, dev, orc = make_cfg4(bz, ref, ny, n, np.float64, density=0.1)
+    mu, y = np.full(ny, 0.1), np.zeros(ny)
+    prob = bz.Problem(*dev, n, ny, np.float64)
+    prob.set_multipliers(mu, y)
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=2.3e-16).c_opts(), np.zeros(n))
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), np.zeros(n))
+    it = ref.PANOCplusIteration(al, ref.NonsmoothCostFun(orc[1]), np.zeros(n), minimum_gamma=2.3e-16)
+    st = it.init()
+    for k in range(15):
+        assert rel(prob.panoc_vector("z"), st.z) <= 1e-9 if np.any(st.z) else True
+        prob.panoc_step()
+        st = it.step(st)
+    prob.close()
+    sub = lambda **kw: bz.PANOCplus(maxit=100000, minimum_gamma=2.3e-16, **kw)
+    subr = lambda **kw: ref.PANOCplus(maxit=100000, minimum_gamma=2.3e-16, **kw)
+    for resident in (True, False):
+        a = bz.alps(*dev, np.zeros(n), np.zeros(ny), subsolver=sub, subsolver_maxit=100000, resident=resident)
+        o = ref.alps(*orc, np.zeros(n), np.zeros(ny), subsolver=subr, subsolver_maxit=100000)
+        assert a[5] == o[5] == "first_order"
+        assert np.max(np.abs(d["A"] @ a[0] - d["b"])) <= 1e-5
+        assert abs(np.sum(np.abs(a[0])) - np.sum(np.abs(o[0]))) <= 1e-4 * np.sum(np.abs(o[0]))
+        assert np.max(np.abs(a[0] - o[0])) <= 1e-4
+
+
+def test_dense_basis_pursuit_recovers_sparse_signal_fp32(bz, ref):
+    """fp32 as in BASELINE config 4 (scaled down): basis pursuit recovers the planted sparse +-1 signal."""
+    ny, n = 256, 1024
+    d, dev, orc = make_cfg4(bz, ref, ny, n, np.float32, density=0.02)
+    sub = lambda **kw: bz.PANOCplus(maxit=20000, minimum_gamma=float(np.finfo(np.float32).eps), **kw)
+    a = bz.alps(*dev, np.zeros(n, np.float32), np.zeros(ny, np.float32), tol=np.float32(1e-4), subsolver=sub,
+                subsolver_maxit=20000)
+    assert a[0].dtype == np.float32
+    assert a[5] == "first_order"
+    assert np.max(np.abs(a[0] - d["xtrue"])) <= 5e-3
+
+
+def test_dense_full_size_gradient_fp32(bz, ref):
+    """BASELINE config 4 size (A 8192 x 65536 fp32 = 2 GiB): the device AL gradient (two GEMVs over A)
+    against numpy's sgemv on the same inputs."""
+    ny, n = 8192, 65536
+    d = bz.synth.basis_pursuit(ny, n, dtype=np.float32)
+    prob = bz.Problem(bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(d["A"], d["b"]), bz.ZeroSet(), n, ny, np.float32)
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    mu = np.full(ny, 0.1, np.float32)
+    y = rng.standard_normal(ny).astype(np.float32)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    t = (d["A"].astype(np.float64) @ x.astype(np.float64) - d["b"] + mu.astype(np.float64) * y) / mu
+    g_ref = d["A"].T.astype(np.float64) @ t if False else (t @ d["A"].astype(np.float64, copy=False))
+    assert np.max(np.abs(g_dev - g_ref)) <= 2e-4 * np.max(np.abs(g_ref))
+    prob.close()

@@ -20,7 +20,7 @@ BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
 NUM_KERNEL_CATEGORIES = 12
 KERNEL_CATEGORIES = ("k_axpy_dot", "k_fused_sep", "al_gradient", "fb_step",
-                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv")
+                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv", "k_twoloop_persist")
 
 
 class CtxOpts(C.Structure):
@@ -45,7 +45,7 @@ class PanocOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("maxit", C.c_int64), ("freq", C.c_int32), ("verbose", C.c_int32),
                 ("minimum_gamma", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("max_backtracks", C.c_int32), ("lbfgs_memory", C.c_int32), ("fuse", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("persist", C.c_int32)]
 
 
 class PanocStats(C.Structure):

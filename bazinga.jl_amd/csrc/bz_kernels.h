@@ -561,6 +561,228 @@ k_gemv_t_finish(const T* __restrict__ part, int nchunks, const T* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------
+// K4, persistent form: the whole L-BFGS two-loop in ONE launch with d held in registers.
+//
+// One 512-thread block per CU (8 waves, 256 VGPRs each: the CU's whole register file); thread t
+// of block b owns packs c(k) = (k*NB + b)*512 + t, k < KR, i.e. up to 40 double2 = 160 VGPRs of
+// d.  The 2m-1 sequentially dependent dot products become grid-wide phases separated by a
+// counter barrier (agent-scope release -> atomic add -> relaxed poll -> agent-scope acquire;
+// partials travel as sc1 stores/loads, every spin is bounded).  Per phase only the two history
+// vectors stream from HBM (d neither re-read nor re-written):
+//   traffic: res + s_1 + 2(m-1) + 1 + 2(m-1) + d_out = 4m passes   vs  8m-3 for the kernel chain.
+// The arithmetic per element and the coefficient formulas are those of k_dot / k_axpy_dot.
+// ---------------------------------------------------------------------------
+constexpr int PBLOCK = 512;
+constexpr int PWAVES = PBLOCK / 64;
+constexpr int PMAXMEM = 16;
+constexpr unsigned PSPIN_LIMIT = 4000000u;
+
+template <class T> struct PersistArgs {
+    const T* res;
+    const T* S[PMAXMEM];     // newest first
+    const T* Y[PMAXMEM];
+    T ys[PMAXMEM];
+    T H;
+    int m;
+    int nb;                  // blocks in the grid (all resident: one per CU)
+    T* d_out;
+    int64_t n;
+    double* parts;
+    double* alphas;
+    unsigned long long* counter;
+    unsigned long long base; // counter value when this launch starts
+    int* timeout;            // host-visible flag, set if a spin gives up
+    int slot_loop1, slot_loop2;
+};
+
+__device__ __forceinline__ double block_sum512(double v, double* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+    __syncthreads();
+    return t;
+}
+
+// publish this block's partial, wait for all blocks, return the folded total (same bits everywhere)
+__device__ __forceinline__ double grid_phase_sum(double acc, double* row, int nb,
+                                                 unsigned long long* counter,
+                                                 unsigned long long target, int* timeout, double* sh) {
+    const double part = block_sum512(acc, sh);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(row + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > PSPIN_LIMIT) { *timeout = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += PBLOCK)
+        v += __hip_atomic_load(row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return block_sum512(v, sh);
+}
+
+template <class T, int KR>
+__global__ void __launch_bounds__(PBLOCK, 2)
+k_twoloop_persist(PersistArgs<T> a) {
+    constexpr int N = PackN<T>::N;
+    __shared__ double sh[PWAVES];
+    __shared__ T alpha_sh[PMAXMEM];
+    __shared__ int stride_sh;
+    const int m = a.m, nb = a.nb;
+    if (threadIdx.x == 0) stride_sh = nb * PBLOCK * N;
+    __syncthreads();
+    Pack<T> d[KR];
+    unsigned long long target = a.base;
+    const int64_t first = ((int64_t)blockIdx.x * PBLOCK + threadIdx.x) * N;
+
+    // Per phase the element stride between a thread's packs is re-read from LDS through a volatile
+    // pointer: it keeps the KR pack offsets from being hoisted out of the phase loops (they would
+    // occupy 2 registers per pack for the whole kernel, next to the 4 per pack that d needs).
+#define BZ_P_BEGIN                                                                      \
+    const int stride_e = *(volatile int*)&stride_sh;                                    \
+    int64_t i0 = first;
+#define BZ_P_CHUNK                                                                      \
+    const bool valid = i0 < a.n;                                                        \
+    const int cnt = !valid ? 0 : ((i0 + N <= a.n) ? N : (int)(a.n - i0));
+#define BZ_P_NEXT i0 += stride_e;
+
+    // phase 0: d = -res ; <s_0, d>
+    double acc = 0.0;
+    {
+        BZ_P_BEGIN
+        const T* __restrict__ pr = a.res;
+        const T* __restrict__ ps = a.S[0];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            BZ_P_CHUNK
+            if (valid) {
+                Pack<T> r = ld(pr, i0, cnt), s = ld(ps, i0, cnt);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    T o = T(-1) * r.v[e];
+                    d[k].v[e] = o;
+                    if (e < cnt) acc += (double)(s.v[e] * o);
+                }
+            } else {
+                d[k] = splat(T(0));
+            }
+            BZ_P_NEXT
+        }
+    }
+    // loop 1: d -= alpha_j y_j ; <s_{j+1}, d>          (j = 0 .. m-2)
+    for (int j = 0; j + 1 < m; ++j) {
+        target += nb;
+        const double tot = grid_phase_sum(acc, a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE, nb, a.counter,
+                                          target, a.timeout, sh);
+        const T al = T(tot) / a.ys[j];
+        if (threadIdx.x == 0) alpha_sh[j] = al;
+        const T coef = -al;
+        const T* __restrict__ yv = a.Y[j];
+        const T* __restrict__ sw = a.S[j + 1];
+        acc = 0.0;
+        BZ_P_BEGIN
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            BZ_P_CHUNK
+            if (valid) {
+                Pack<T> v = ld(yv, i0, cnt), w = ld(sw, i0, cnt);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    T t = coef * v.v[e];
+                    T o = d[k].v[e] + t;
+                    d[k].v[e] = o;
+                    if (e < cnt) acc += (double)(w.v[e] * o);
+                }
+            }
+            BZ_P_NEXT
+        }
+    }
+    // middle: d = H (d - alpha_{m-1} y_{m-1}) ; <y_{m-1}, d>
+    {
+        const int j = m - 1;
+        target += nb;
+        const double tot = grid_phase_sum(acc, a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE, nb, a.counter,
+                                          target, a.timeout, sh);
+        const T al = T(tot) / a.ys[j];
+        if (threadIdx.x == 0) alpha_sh[j] = al;
+        const T coef = -al;
+        const T* __restrict__ yv = a.Y[j];
+        acc = 0.0;
+        BZ_P_BEGIN
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            BZ_P_CHUNK
+            if (valid) {
+                Pack<T> v = ld(yv, i0, cnt);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    T t = coef * v.v[e];
+                    T o = d[k].v[e] + t;
+                    o = a.H * o;
+                    d[k].v[e] = o;
+                    if (e < cnt) acc += (double)(v.v[e] * o);
+                }
+            }
+            BZ_P_NEXT
+        }
+    }
+    __syncthreads();    // alpha_sh complete
+    // loop 2: d += (alpha_j - beta_j) s_j ; <y_{j-1}, d>   (j = m-1 .. 1)
+    for (int j = m - 1; j >= 1; --j) {
+        target += nb;
+        const double tot = grid_phase_sum(acc, a.parts + (size_t)(a.slot_loop2 + j) * PSTRIDE, nb, a.counter,
+                                          target, a.timeout, sh);
+        const T beta = T(tot) / a.ys[j];
+        const T coef = alpha_sh[j] - beta;
+        const T* __restrict__ sv = a.S[j];
+        const T* __restrict__ yw = a.Y[j - 1];
+        acc = 0.0;
+        BZ_P_BEGIN
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            BZ_P_CHUNK
+            if (valid) {
+                Pack<T> v = ld(sv, i0, cnt), w = ld(yw, i0, cnt);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    T t = coef * v.v[e];
+                    T o = d[k].v[e] + t;
+                    d[k].v[e] = o;
+                    if (e < cnt) acc += (double)(w.v[e] * o);
+                }
+            }
+            BZ_P_NEXT
+        }
+    }
+    // last partial (<y_0, d>) and d go to memory: the next kernel fuses the final axpy
+    {
+        const double part = block_sum512(acc, sh);
+        if (threadIdx.x == 0) a.parts[(size_t)(a.slot_loop2 + 0) * PSTRIDE + blockIdx.x] = part;
+        if (blockIdx.x == 0 && threadIdx.x < m) a.alphas[threadIdx.x] = (double)alpha_sh[threadIdx.x];
+    }
+    {
+        BZ_P_BEGIN
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            BZ_P_CHUNK
+            if (valid) st(a.d_out, i0, cnt, d[k]);
+            BZ_P_NEXT
+        }
+    }
+#undef BZ_P_BEGIN
+#undef BZ_P_CHUNK
+#undef BZ_P_NEXT
+}
+
+// ---------------------------------------------------------------------------
 // K3: forward-backward step  y = x - gamma*g ; z = prox(y) ; res = x - z
 //   slots: +0 sum g terms (multiply by lambda on the host), +1 <g,res>, +2 ||res||^2
 //   g == nullptr: pure prox of x (used for prox_{eps g}(x0), alps.jl:38)

@@ -45,7 +45,7 @@ k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, doub
 }
 
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
-                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9 };
+                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10 };
 
 template <class T> class Solver final : public SolverBase {
    public:
@@ -139,6 +139,16 @@ template <class T> class Solver final : public SolverBase {
         recv_.alloc((size_t)SL_COUNT * std::max(1, ctx->nranks));
         BZ_HIP(hipHostMalloc((void**)&host_out_, sizeof(double) * MAX_COLLECT, hipHostMallocMapped));
         BZ_HIP(hipHostGetDevicePointer((void**)&host_out_dev_, host_out_, 0));
+        BZ_HIP(hipHostMalloc((void**)&ptimeout_, sizeof(int), hipHostMallocMapped));
+        *ptimeout_ = 0;
+        BZ_HIP(hipHostGetDevicePointer((void**)&ptimeout_dev_, ptimeout_, 0));
+        pcounter_.alloc(2);
+        BZ_HIP(hipMemsetAsync(pcounter_.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        {
+            hipDeviceProp_t prop;
+            BZ_HIP(hipGetDeviceProperties(&prop, ctx->device));
+            num_cus = prop.multiProcessorCount;
+        }
         for (int s = 0; s < SL_COUNT; ++s) { grp_first[s] = s; grp_cnt[s] = 1; slot_n[s] = grid; }
         slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
         BZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -148,6 +158,7 @@ template <class T> class Solver final : public SolverBase {
         for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto& e : ev_pool) (void)hipEventDestroy(e);
         if (host_out_) (void)hipHostFree(host_out_);
+        if (ptimeout_) (void)hipHostFree(ptimeout_);
     }
 
     // ------------------------------------------------------------------ API
@@ -362,6 +373,13 @@ template <class T> class Solver final : public SolverBase {
     DBuf<T> X_[3], RES_[2], Z_[2], GX_, GZ_, D_, TMP_;
     DBuf<T> A_, cb_, CX_, YU_, GT_;          // DenseAffine c: A[ny][n], b, c(x), yupd, A'v row-chunk partials
     int rows_per_chunk = 1, nrowchunks = 1;
+    // persistent two-loop
+    DBuf<unsigned long long> pcounter_;
+    unsigned long long pbase = 0;
+    int* ptimeout_ = nullptr;                // host-mapped
+    int* ptimeout_dev_ = nullptr;
+    int num_cus = 0;
+    bool persist_ok = false;
     std::vector<DBuf<T>> S_, Y_;
     DBuf<double> parts_, alphas_, send_, recv_;
     double* host_out_ = nullptr;
@@ -480,6 +498,10 @@ template <class T> class Solver final : public SolverBase {
         }
         launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
         BZ_HIP(hipStreamSynchronize(ctx->stream));
+        if (*ptimeout_) {
+            *ptimeout_ = 0;
+            throw Error(BZ_ERR_HIP, "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)");
+        }
         return std::vector<double>(host_out_, host_out_ + a.n);
     }
 
@@ -568,11 +590,50 @@ template <class T> class Solver final : public SolverBase {
     }
 
     // d = H(-res) up to the last axpy, which the caller fuses with what follows
+    // same result through the persistent kernel (one launch, d register-resident)
+    TailArgs<T> two_loop_persist() {
+        TailArgs<T> t;
+        std::memset(&t, 0, sizeof(t));
+        t.alphas = alphas_.p;
+        const int m = (int)order.size();
+        PersistArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        a.res = RES_[rc].p;
+        for (int j = 0; j < m; ++j) { a.S[j] = S_[order[j]].p; a.Y[j] = Y_[order[j]].p; a.ys[j] = ys_[order[j]]; }
+        a.H = H; a.m = m; a.nb = num_cus; a.d_out = D_.p; a.n = n; a.parts = parts_.p; a.alphas = alphas_.p;
+        a.counter = pcounter_.p; a.base = pbase; a.timeout = ptimeout_dev_;
+        a.slot_loop1 = SL_LOOP1; a.slot_loop2 = SL_LOOP2;
+        pbase += (unsigned long long)(2 * m - 1) * num_cus;
+        const int64_t nchunks = (n + PackN<T>::N - 1) / PackN<T>::N;
+        const int64_t kneed = (nchunks + (int64_t)num_cus * PBLOCK - 1) / ((int64_t)num_cus * PBLOCK);
+        if (kneed <= 8) launch_persist(k_twoloop_persist<T, 8>, a);
+        else if (kneed <= 16) launch_persist(k_twoloop_persist<T, 16>, a);
+        else if (kneed <= 24) launch_persist(k_twoloop_persist<T, 24>, a);
+        else if (kneed <= 32) launch_persist(k_twoloop_persist<T, 32>, a);
+        else launch_persist(k_twoloop_persist<T, 40>, a);
+        slot_n[SL_LOOP2 + 0] = num_cus;
+        t.in = D_.p; t.sgn = T(1); t.v = S_[order[0]].p; t.mode = 1; t.j = 0; t.apply_H = 0; t.H = T(1);
+        t.src = src(SL_LOOP2 + 0); t.ys = ys_[order[0]];
+        return t;
+    }
+    template <class K> void launch_persist(K kernel, const PersistArgs<T>& a) {
+        ProfRec r{C_PERSIST, nullptr, nullptr};
+        if ((prof_mask >> C_PERSIST) & 1u) {
+            r.a = get_event(); r.b = get_event();
+            hipExtLaunchKernelGGL(kernel, dim3(num_cus), dim3(PBLOCK), 0, ctx->stream, r.a, r.b, 0, a);
+            prof_recs.push_back(r);
+        } else {
+            hipLaunchKernelGGL(kernel, dim3(num_cus), dim3(PBLOCK), 0, ctx->stream, a);
+        }
+        BZ_HIP(hipGetLastError());
+    }
+
     TailArgs<T> two_loop() {
         TailArgs<T> t;
         std::memset(&t, 0, sizeof(t));
         t.alphas = alphas_.p;
         const int m = (int)order.size();
+        slot_n[SL_LOOP2 + 0] = grid;
         const T* res = RES_[rc].p;
         if (m == 0) {
             t.in = res; t.v = nullptr; t.sgn = T(-1); t.mode = 2; t.apply_H = 1; t.H = H;
@@ -625,6 +686,15 @@ template <class T> class Solver final : public SolverBase {
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
         fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
+        {
+            // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
+            // block per CU) and the vector must be long enough for 2m-1 grid barriers to beat 2m launches
+            const int64_t nchunks = (n + PackN<T>::N - 1) / PackN<T>::N;
+            const int64_t kneed = (nchunks + (int64_t)num_cus * PBLOCK - 1) / ((int64_t)num_cus * PBLOCK);
+            int64_t min_n = 2000000;
+            if (const char* e = getenv("BZ_PERSIST_MIN_N")) min_n = atoll(e);
+            persist_ok = o.persist && !ctx->comm && num_cus > 0 && num_cus <= PSTRIDE && kneed <= 40 && n >= min_n;
+        }
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;
         last_nbt = 0; last_fused = false; tau = T(0); last_ys = T(0); fbe_last = T(0);
@@ -708,7 +778,8 @@ template <class T> class Solver final : public SolverBase {
         const T FBE_x = (f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr0 * nr0)) + g_z;
         fbe_last = FBE_x;
         // direction d = H(-res): all but the last axpy
-        TailArgs<T> tail = two_loop();
+        const bool use_persist = persist_ok && !order.empty();
+        TailArgs<T> tail = use_persist ? two_loop_persist() : two_loop();
         tau = T(1);
         const int xp = xc, xd = (xc + 1) % 3, xb = (xc + 2) % 3;
         const int rp = rc, rn = 1 - rc, zp = zc, zn = 1 - zc;

@@ -101,13 +101,14 @@ class PANOCplus:
     AugLagFun and `g` a NonsmoothCostFun over lowered oracle types."""
 
     def __init__(self, *, directions=None, maxit=1000, tol=1e-8, verbose=False, freq=10,
-                 minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, ctx=None):
+                 minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, persist=True,
+                 ctx=None):
         self.directions = directions if directions is not None else LBFGS(5)
         if not isinstance(self.directions, LBFGS):
             raise UnsupportedOracle("only directions=LBFGS(M) is lowered to the device")
         self.maxit, self.tol, self.verbose, self.freq = maxit, tol, verbose, freq
         self.minimum_gamma, self.alpha, self.beta = minimum_gamma, alpha, beta
-        self.max_backtracks, self.fuse, self.ctx = max_backtracks, fuse, ctx
+        self.max_backtracks, self.fuse, self.persist, self.ctx = max_backtracks, fuse, persist, ctx
         self.stats = None
 
     def c_opts(self) -> L.PanocOpts:
@@ -117,6 +118,7 @@ class PANOCplus:
         o.freq, o.verbose = int(min(self.freq, 2 ** 31 - 1)), int(bool(self.verbose))
         o.minimum_gamma, o.alpha, o.beta = float(self.minimum_gamma), float(self.alpha), float(self.beta)
         o.max_backtracks, o.lbfgs_memory, o.fuse = int(self.max_backtracks), self.directions.memory, int(bool(self.fuse))
+        o.persist = int(bool(self.persist))
         return o
 
     def __call__(self, *, f, g, x0):

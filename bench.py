@@ -55,12 +55,75 @@ def cpu_baseline(n, states):
             "host_cpus": os.cpu_count()}
 
 
+def side_workload(args):
+    """cfg 3 / cfg 4 (single GPU): the other BASELINE configs, same JSON shape; not the headline."""
+    import torch
+    import bazinga_jl_amd as bz
+    eps64, eps32 = float(np.finfo(np.float64).eps), float(np.finfo(np.float32).eps)
+    if args.workload == "cfg3":
+        d = bz.synth.obstacle_grid(2048)
+        n = ny = 2048 * 2048
+        dt, w = np.float64, 8
+        prob = bz.Problem(bz.Stencil5ptQuadratic(2048, 2048, d["b"]), bz.Zero(), bz.IdentityFunction(),
+                          bz.ClosedSet(bz.IndBox(d["psi"], np.inf)), n, ny, dt)
+        x0, mg = d["x0"], eps64
+        b_iter = 63 * w * n            # SURVEY §8(d): 63 passes
+        cat_name, label = "k_axpy_dot", "cfg3: 5-pt stencil QP on 2048^2 grid fp64, box D, g=Zero, LBFGS(5)"
+        launch_bytes = lambda m: ((4.0 * (2 * m - 2) + 3.0) / (2 * m - 1)) * w * n
+        kernel = "bz::k_axpy_dot<double>"
+    else:
+        ny, n = 8192, 65536
+        d = bz.synth.basis_pursuit(ny, n, dtype=np.float32)
+        dt, w = np.float32, 4
+        prob = bz.Problem(bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(d["A"], d["b"]), bz.ZeroSet(), n, ny, dt)
+        x0, mg = np.zeros(n, dt), eps32
+        b_iter = 4 * ny * n * w        # A read twice per AL gradient, 2 AL gradients per iteration
+        cat_name, label = "gemv", "cfg4: basis pursuit, dense A 8192x65536 fp32, l1 prox, D=ZeroSet, LBFGS(5)"
+        launch_bytes = lambda m: ny * n * w
+        kernel = "bz::k_gemv_n<float> / bz::k_gemv_t<float>"
+    prob.set_multipliers(np.full(ny, 0.1, dt), np.zeros(ny, dt))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=mg).c_opts(), x0)
+    for _ in range(args.warmup):
+        prob.panoc_step()
+    cat = bz._lib.KERNEL_CATEGORIES.index(cat_name)
+    prob.profile_reset()
+    prob.profile_enable(1 << cat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prob.panoc_step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prob.profile_enable(False)
+    prof = prob.profile()[cat_name]
+    sc = prob.panoc_scalars()
+    its = args.steps / elapsed
+    avg_s = (prof["total_ms"] / 1e3) / max(1, prof["launches"])
+    achieved = launch_bytes(max(1, int(sc["lbfgs_mem"]))) / avg_s / 1e9
+    print(json.dumps({
+        "metric": "PANOC inner iterations/sec (%s)" % args.workload, "value": round(its, 3), "unit": "iterations/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if w == 8 else "f32",
+        "data": "synthetic", "config": {"workload": label, "n": n, "ny": ny},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                     "avg_launch_us": round(avg_s * 1e6, 3), "launches_per_iteration": prof["launches"] / args.steps},
+        "roofline_iteration": {"algorithmic_bytes_per_iteration": int(b_iter), "achieved": round(b_iter * its / 1e9, 1),
+                               "unit": "GB/s", "frac": round(b_iter * its / 1e9 / HBM_PEAK_GBS, 4)},
+        "solver": {"gamma": sc["gamma"], "stop_norm": sc["stop_norm"], "k": int(sc["k"]), "lbfgs_mem": int(sc["lbfgs_mem"])},
+        "cpu_baseline": None}), flush=True)
+    prob.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=float, default=1e7, help="global problem size (default: BASELINE cfg 2)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 (default, the headline metric); cfg3 2048^2 stencil QP; cfg4 dense-A basis "
+                         "pursuit fp32; cfg5 = cfg2 at n=1e8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-states", type=int, default=13)
     ap.add_argument("--no-fuse", action="store_true")
@@ -70,6 +133,10 @@ def main():
     import bazinga_jl_amd as bz
 
     n = int(args.n)
+    if args.workload == "cfg5":
+        n = 100_000_000
+    if args.workload in ("cfg3", "cfg4"):
+        return side_workload(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,12 +215,12 @@ def main():
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         b_iter = algorithmic_bytes_per_iter(n, n_al=2, n_fb=1)
         out = {
-            "metric": "PANOC inner iterations/sec, n=10^7 l1-quadratic",
+            "metric": "PANOC inner iterations/sec, n=10^7 l1-quadratic" if n == 10_000_000 else "PANOC inner iterations/sec, n=%d l1-quadratic" % n,
             "value": round(its, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "cfg2: l1-regularised diagonal quadratic, n=%d fp64, soft-threshold prox_g, "
+            "config": {"workload": args.workload + ": l1-regularised diagonal quadratic, n=%d fp64, soft-threshold prox_g, "
                                    "c=Identity, D=Box[-1,1], LBFGS(5), mu=0.1, y=0, tol=0" % n,
                        "n": n, "n_per_gpu": nl, "lbfgs_memory": M_LBFGS,
                        "parallelism": "single GPU" if world == 1 else f"x sharded over {world} GPUs, scalar all-gather"},

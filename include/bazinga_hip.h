@@ -130,7 +130,10 @@ typedef struct {
     int32_t fuse;            /* 1: use the single-pass fused kernel when the problem
                                 is separable (elementwise f, c = Identity); 0: always
                                 the generic kernel chain.  Results are bit-identical. */
-    int32_t reserved;
+    int32_t persist;         /* 1: run the L-BFGS two-loop as ONE persistent launch with d
+                                register-resident when the vector fits (<= 40 packs/thread)
+                                and is long enough; 0: one kernel per two-loop step.
+                                Same arithmetic, different (fixed) summation tree.       */
 } bz_panoc_opts;
 
 void bz_panoc_default_opts(bz_panoc_opts* o);
@@ -219,7 +222,7 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
 /* category: 0 k_axpy_dot (two-loop step), 1 k_fused_sep (fused separable iteration),
  *           2 AL gradient, 3 forward-backward step, 4 L-BFGS update/stop norm,
  *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot),
- *           9 dense GEMV kernels.
+ *           9 dense GEMV kernels, 10 k_twoloop_persist.
  * mask: bit c enables timing of category c (0 = off, -1 = all).                     */
 #define BZ_NUM_KERNEL_CATEGORIES 12
 int bz_profile_enable(bz_problem* p, int32_t mask);

@@ -20,7 +20,7 @@ BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
 NUM_KERNEL_CATEGORIES = 12
 KERNEL_CATEGORIES = ("k_axpy_dot", "k_fused_sep", "al_gradient", "fb_step",
-                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv", "k_twoloop_persist")
+                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv", "k_twoloop_persist", "k_gemv_t_mfma")
 
 
 class CtxOpts(C.Structure):

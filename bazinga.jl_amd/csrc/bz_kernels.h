@@ -527,6 +527,59 @@ k_gemv_t(const T* __restrict__ A, const T* __restrict__ v, T* __restrict__ part,
     *reinterpret_cast<Pack<T>*>(part + (int64_t)blockIdx.y * n + c * N) = o;
 }
 
+// jtv partials on the matrix cores (fp32): v_mfma_f32_16x16x4_f32 with the matrix tile as the B
+// operand — lane l feeds B[k = l>>4][col = l&15] = A[i + (l>>4)][j0 + 4(l&15) + q], one 16-B load
+// per lane covering q = 0..3, so a wave-load is 4 rows x 256 B contiguous — and v as the A operand
+// in row 0 only (A[m = l&15][k = l>>4] = v[i + k] for m == 0, else 0).  Row 0 of D (lanes 0..15,
+// register 0) then accumulates sum_i v[i] A[i][j] as an exact k-ordered fmaf chain.  15/16 of the
+// MFMA work is padding: a GEMV has no reuse, the kernel stays bound by the bytes of A (the f32 MFMA
+// ingests 32 B/clk/CU = 19.7 TB/s chip-wide, 3x the HBM rate).  Four accumulators (one per q) cover
+// the 40-cycle dependent-accumulator latency.  Same partial layout as k_gemv_t.
+typedef float bz_f32x4 __attribute__((ext_vector_type(4)));
+
+static __global__ void __launch_bounds__(BLOCK)
+k_gemv_t_mfma(const float* __restrict__ A, const float* __restrict__ v, float* __restrict__ part,
+              int64_t ny, int64_t n, int rows_per_chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = ((int64_t)blockIdx.x * WAVES + wave) * 64;      // 64 columns per wave
+    if (j0 >= n) return;                                              // wave-uniform
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = (r0 + rows_per_chunk < ny) ? r0 + rows_per_chunk : ny;
+    const int k = lane >> 4, c = lane & 15;
+    const float* col = A + j0 + 4 * c;
+    bz_f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    int64_t i = r0;
+    for (; i + 8 <= r1; i += 8) {                                     // two 4-row steps in flight
+        const Pack<float> ma = *reinterpret_cast<const Pack<float>*>(col + (i + k) * n);
+        const Pack<float> mb = *reinterpret_cast<const Pack<float>*>(col + (i + 4 + k) * n);
+        const float va = (c == 0) ? v[i + k] : 0.0f;
+        const float vb = (c == 0) ? v[i + 4 + k] : 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[3], acc3, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, mb.v[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, mb.v[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, mb.v[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, mb.v[3], acc3, 0, 0, 0);
+    }
+    for (; i < r1; i += 4) {                                          // ragged tail: rows beyond r1 feed zeros
+        const bool ok = (i + k) < r1;
+        Pack<float> ma = splat(0.0f);
+        if (ok) ma = *reinterpret_cast<const Pack<float>*>(col + (i + k) * n);
+        const float va = (ok && c == 0) ? v[i + k] : 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[3], acc3, 0, 0, 0);
+    }
+    if (lane < 16) {                                                  // D row 0 = lanes 0..15, register 0
+        Pack<float> o;
+        o.v[0] = acc0[0]; o.v[1] = acc1[0]; o.v[2] = acc2[0]; o.v[3] = acc3[0];
+        *reinterpret_cast<Pack<float>*>(part + (int64_t)blockIdx.y * n + j0 + 4 * lane) = o;
+    }
+}
+
 // dlx = dfx + jtv with jtv = sum over row chunks (fixed order) ; f element-wise (Zero|DiagQuadratic)
 //   slot +0: sum f terms
 template <class T>
@@ -629,6 +682,39 @@ __device__ __forceinline__ double grid_phase_sum(double acc, double* row, int nb
     return block_sum512(v, sh);
 }
 
+// Stream KR rounds of one or two vectors past the register-resident d with an explicit two-deep
+// software pipeline: the loads of the next group of G rounds are issued before the current group
+// is consumed, and sched_barriers keep the compiler from sinking them back to their uses (with d
+// holding 160 of the 256 VGPRs its scheduler otherwise keeps only 2 loads in flight).
+template <class T, int KR, int G, bool TWO, class F>
+__device__ __forceinline__ void persist_stream(const T* __restrict__ p0, const T* __restrict__ p1,
+                                               int64_t first, int stride_e, F&& f) {
+    static_assert(KR % G == 0, "KR must be a multiple of the pipeline group");
+    Pack<T> bv[2][G], bw[2][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t i0 = first + (int64_t)g * stride_e;
+        bv[0][g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
+        if (TWO) bw[0][g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KR; kb += G) {
+        const int cur = (kb / G) & 1, nxt = cur ^ 1;
+        if (kb + G < KR) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int64_t i0 = first + (int64_t)(kb + G + g) * stride_e;
+                bv[nxt][g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
+                if (TWO) bw[nxt][g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) f(kb + g, bv[cur][g], TWO ? bw[cur][g] : bv[cur][g]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <class T, int KR>
 __global__ void __launch_bounds__(PBLOCK, 2)
 k_twoloop_persist(PersistArgs<T> a) {
@@ -646,37 +732,24 @@ k_twoloop_persist(PersistArgs<T> a) {
     // Per phase the element stride between a thread's packs is re-read from LDS through a volatile
     // pointer: it keeps the KR pack offsets from being hoisted out of the phase loops (they would
     // occupy 2 registers per pack for the whole kernel, next to the 4 per pack that d needs).
-#define BZ_P_BEGIN                                                                      \
-    const int stride_e = *(volatile int*)&stride_sh;                                    \
-    int64_t i0 = first;
-#define BZ_P_CHUNK                                                                      \
-    const bool valid = i0 < a.n;                                                        \
-    const int cnt = !valid ? 0 : ((i0 + N <= a.n) ? N : (int)(a.n - i0));
-#define BZ_P_NEXT i0 += stride_e;
+    // Every vector this kernel touches is allocated zero-padded to KR*nb*512 packs (host side), so all
+    // rounds of all threads are in-bounds and the padding contributes exact zeros: no masks, no
+    // branches.  The element stride between a thread's packs is re-read per phase through a volatile
+    // LDS pointer so the KR pack offsets are not hoisted out of the phase loops (2 VGPRs each).
+#define BZ_P_STRIDE (*(volatile int*)&stride_sh)
+    constexpr int G = 4;
 
     // phase 0: d = -res ; <s_0, d>
     double acc = 0.0;
-    {
-        BZ_P_BEGIN
-        const T* __restrict__ pr = a.res;
-        const T* __restrict__ ps = a.S[0];
+    persist_stream<T, KR, G, true>(a.res, a.S[0], first, BZ_P_STRIDE,
+        [&](int k, const Pack<T>& r, const Pack<T>& s) {
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            BZ_P_CHUNK
-            if (valid) {
-                Pack<T> r = ld(pr, i0, cnt), s = ld(ps, i0, cnt);
-#pragma unroll
-                for (int e = 0; e < N; ++e) {
-                    T o = T(-1) * r.v[e];
-                    d[k].v[e] = o;
-                    if (e < cnt) acc += (double)(s.v[e] * o);
-                }
-            } else {
-                d[k] = splat(T(0));
+            for (int e = 0; e < N; ++e) {
+                T o = T(-1) * r.v[e];
+                d[k].v[e] = o;
+                acc += (double)(s.v[e] * o);
             }
-            BZ_P_NEXT
-        }
-    }
+        });
     // loop 1: d -= alpha_j y_j ; <s_{j+1}, d>          (j = 0 .. m-2)
     for (int j = 0; j + 1 < m; ++j) {
         target += nb;
@@ -685,25 +758,17 @@ k_twoloop_persist(PersistArgs<T> a) {
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
         const T coef = -al;
-        const T* __restrict__ yv = a.Y[j];
-        const T* __restrict__ sw = a.S[j + 1];
         acc = 0.0;
-        BZ_P_BEGIN
-#pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            BZ_P_CHUNK
-            if (valid) {
-                Pack<T> v = ld(yv, i0, cnt), w = ld(sw, i0, cnt);
+        persist_stream<T, KR, G, true>(a.Y[j], a.S[j + 1], first, BZ_P_STRIDE,
+            [&](int k, const Pack<T>& v, const Pack<T>& w) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
                     T t = coef * v.v[e];
                     T o = d[k].v[e] + t;
                     d[k].v[e] = o;
-                    if (e < cnt) acc += (double)(w.v[e] * o);
+                    acc += (double)(w.v[e] * o);
                 }
-            }
-            BZ_P_NEXT
-        }
+            });
     }
     // middle: d = H (d - alpha_{m-1} y_{m-1}) ; <y_{m-1}, d>
     {
@@ -714,25 +779,19 @@ k_twoloop_persist(PersistArgs<T> a) {
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
         const T coef = -al;
-        const T* __restrict__ yv = a.Y[j];
+        const T Hs = a.H;
         acc = 0.0;
-        BZ_P_BEGIN
-#pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            BZ_P_CHUNK
-            if (valid) {
-                Pack<T> v = ld(yv, i0, cnt);
+        persist_stream<T, KR, G, false>(a.Y[j], a.Y[j], first, BZ_P_STRIDE,
+            [&](int k, const Pack<T>& v, const Pack<T>&) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
                     T t = coef * v.v[e];
                     T o = d[k].v[e] + t;
-                    o = a.H * o;
+                    o = Hs * o;
                     d[k].v[e] = o;
-                    if (e < cnt) acc += (double)(v.v[e] * o);
+                    acc += (double)(v.v[e] * o);
                 }
-            }
-            BZ_P_NEXT
-        }
+            });
     }
     __syncthreads();    // alpha_sh complete
     // loop 2: d += (alpha_j - beta_j) s_j ; <y_{j-1}, d>   (j = m-1 .. 1)
@@ -742,25 +801,17 @@ k_twoloop_persist(PersistArgs<T> a) {
                                           target, a.timeout, sh);
         const T beta = T(tot) / a.ys[j];
         const T coef = alpha_sh[j] - beta;
-        const T* __restrict__ sv = a.S[j];
-        const T* __restrict__ yw = a.Y[j - 1];
         acc = 0.0;
-        BZ_P_BEGIN
-#pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            BZ_P_CHUNK
-            if (valid) {
-                Pack<T> v = ld(sv, i0, cnt), w = ld(yw, i0, cnt);
+        persist_stream<T, KR, G, true>(a.S[j], a.Y[j - 1], first, BZ_P_STRIDE,
+            [&](int k, const Pack<T>& v, const Pack<T>& w) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
                     T t = coef * v.v[e];
                     T o = d[k].v[e] + t;
                     d[k].v[e] = o;
-                    if (e < cnt) acc += (double)(w.v[e] * o);
+                    acc += (double)(w.v[e] * o);
                 }
-            }
-            BZ_P_NEXT
-        }
+            });
     }
     // last partial (<y_0, d>) and d go to memory: the next kernel fuses the final axpy
     {
@@ -769,17 +820,12 @@ k_twoloop_persist(PersistArgs<T> a) {
         if (blockIdx.x == 0 && threadIdx.x < m) a.alphas[threadIdx.x] = (double)alpha_sh[threadIdx.x];
     }
     {
-        BZ_P_BEGIN
+        const int stride_e = BZ_P_STRIDE;
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            BZ_P_CHUNK
-            if (valid) st(a.d_out, i0, cnt, d[k]);
-            BZ_P_NEXT
-        }
+        for (int k = 0; k < KR; ++k)
+            *reinterpret_cast<Pack<T>*>(a.d_out + first + (int64_t)k * stride_e) = d[k];
     }
-#undef BZ_P_BEGIN
-#undef BZ_P_CHUNK
-#undef BZ_P_NEXT
+#undef BZ_P_STRIDE
 }
 
 // ---------------------------------------------------------------------------

@@ -51,10 +51,13 @@ template <class T> struct DBuf {
     DBuf() = default;
     DBuf(const DBuf&) = delete;
     DBuf& operator=(const DBuf&) = delete;
-    void alloc(size_t count) {
+    void alloc(size_t count) {      // zero-filled, with >= 8 elements of slack behind the payload
         release();
         n = count;
-        if (count) BZ_HIP(hipMalloc((void**)&p, (count + 8) * sizeof(T)));
+        if (count) {
+            BZ_HIP(hipMalloc((void**)&p, (count + 8) * sizeof(T)));
+            BZ_HIP(hipMemset(p, 0, (count + 8) * sizeof(T)));
+        }
     }
     void release() {
         if (p) (void)hipFree(p);

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 
 namespace bz {
 
@@ -45,7 +46,7 @@ k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, doub
 }
 
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
-                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10 };
+                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11 };
 
 template <class T> class Solver final : public SolverBase {
    public:
@@ -80,6 +81,17 @@ template <class T> class Solver final : public SolverBase {
             throw Error(BZ_ERR_ARG, "parameter lambda must be nonnegative");
         BZ_HIP(hipSetDevice(ctx->device));
         const int64_t nchunks = (n + PackN<T>::N - 1) / PackN<T>::N;
+        {
+            hipDeviceProp_t prop;
+            BZ_HIP(hipGetDeviceProperties(&prop, ctx->device));
+            num_cus = prop.multiProcessorCount;
+            // persistent two-loop: one 512-thread block per CU, KR register packs per thread; its vectors
+            // are zero-padded to KR*num_cus*512 packs so that every round is in-bounds (no masks)
+            const int64_t kneed = (nchunks + (int64_t)num_cus * PBLOCK - 1) / ((int64_t)num_cus * PBLOCK);
+            persist_kr = (kneed <= 40 && num_cus > 0 && num_cus <= PSTRIDE) ? (int)(4 * ((kneed + 3) / 4)) : 0;
+            vcap = n;
+            if (persist_kr) vcap = std::max<int64_t>(n, (int64_t)persist_kr * num_cus * PBLOCK * PackN<T>::N);
+        }
         int g = (int)std::min<int64_t>(PSTRIDE, std::max<int64_t>(1, (nchunks + BLOCK - 1) / BLOCK));
         if (const char* e = getenv("BZ_GRID")) g = std::max(1, std::min(PSTRIDE, atoi(e)));
         grid = g;
@@ -128,10 +140,10 @@ template <class T> class Solver final : public SolverBase {
         }
         mu_.alloc(ny); muy_.alloc(ny); ymul_.alloc(ny); sproj_.alloc(ny);
         P.mu = mu_.p; P.muy = muy_.p;
-        for (auto& b : X_) b.alloc(n);
-        for (auto& b : RES_) b.alloc(n);
-        for (auto& b : Z_) b.alloc(n);
-        GX_.alloc(n); GZ_.alloc(n); D_.alloc(n); TMP_.alloc(n);
+        for (auto& b : X_) b.alloc(vcap);
+        for (auto& b : RES_) b.alloc(vcap);
+        for (auto& b : Z_) b.alloc(vcap);
+        GX_.alloc(vcap); GZ_.alloc(vcap); D_.alloc(vcap); TMP_.alloc(vcap);
         parts_.alloc((size_t)SL_COUNT * PSTRIDE);
         BZ_HIP(hipMemsetAsync(parts_.p, 0, (size_t)SL_COUNT * PSTRIDE * sizeof(double), ctx->stream));
         alphas_.alloc(MAX_MEM + 1);
@@ -144,11 +156,6 @@ template <class T> class Solver final : public SolverBase {
         BZ_HIP(hipHostGetDevicePointer((void**)&ptimeout_dev_, ptimeout_, 0));
         pcounter_.alloc(2);
         BZ_HIP(hipMemsetAsync(pcounter_.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        {
-            hipDeviceProp_t prop;
-            BZ_HIP(hipGetDeviceProperties(&prop, ctx->device));
-            num_cus = prop.multiProcessorCount;
-        }
         for (int s = 0; s < SL_COUNT; ++s) { grp_first[s] = s; grp_cnt[s] = 1; slot_n[s] = grid; }
         slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
         BZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -378,7 +385,8 @@ template <class T> class Solver final : public SolverBase {
     unsigned long long pbase = 0;
     int* ptimeout_ = nullptr;                // host-mapped
     int* ptimeout_dev_ = nullptr;
-    int num_cus = 0;
+    int num_cus = 0, persist_kr = 0;
+    int64_t vcap = 0;                        // allocated elements per n-vector (>= n, zero-padded)
     bool persist_ok = false;
     std::vector<DBuf<T>> S_, Y_;
     DBuf<double> parts_, alphas_, send_, recv_;
@@ -524,14 +532,26 @@ template <class T> class Solver final : public SolverBase {
     void eval_c(const T* x) {
         launch(C_GEMV, k_gemv_n<T>, (int)std::min<int64_t>(ny, 65535), (const T*)A_.p, x, (const T*)cb_.p, CX_.p, ny, n);
     }
+    // jtprod!(jtv, c, x, yupd): fp32 with n % 64 == 0 runs on the matrix cores (v_mfma_f32_16x16x4_f32),
+    // everything else on the vector ALUs; both are bound by the bytes of A.
+    void gemv_t() {
+        if constexpr (std::is_same<T, float>::value) {
+            if (n % 64 == 0 && !getenv("BZ_GEMV_VALU")) {
+                launch2d(C_GEMV_MFMA, k_gemv_t_mfma, (int)((n / 64 + WAVES - 1) / WAVES), nrowchunks,
+                         (const float*)A_.p, (const float*)YU_.p, (float*)GT_.p, ny, n, rows_per_chunk);
+                return;
+            }
+        }
+        const int colblocks = (int)((n / PackN<T>::N + BLOCK - 1) / BLOCK);
+        launch2d(C_GEMV, k_gemv_t<T>, colblocks, nrowchunks, (const T*)A_.p, (const T*)YU_.p, GT_.p, ny, n,
+                 rows_per_chunk);
+    }
     void algrad(const T* x, T* grad, int slot0) {
         if (desc.c_kind == BZ_C_DENSE_AFFINE) {
             eval_c(x);                                                        // cx = A x - b
             launch(C_MISC, k_yupd<T>, grid_y, (const T*)CX_.p, P, YU_.p, ny, parts_.p, slot0 + 1);
             slot_n[slot0] = grid; slot_n[slot0 + 1] = grid_y;
-            const int colblocks = (int)((n / PackN<T>::N + BLOCK - 1) / BLOCK);
-            launch2d(C_GEMV, k_gemv_t<T>, colblocks, nrowchunks, (const T*)A_.p, (const T*)YU_.p, GT_.p, ny, n,
-                     rows_per_chunk);                                         // jtv = A' yupd (row-chunk partials)
+            gemv_t();                                                         // jtv = A' yupd (row-chunk partials)
             launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, x, P, grad, n, parts_.p, slot0);
             gather(slot0, 2, 0u);
             return;
@@ -568,7 +588,7 @@ template <class T> class Solver final : public SolverBase {
         if ((int)S_.size() == M + 1) return;
         S_ = std::vector<DBuf<T>>(M + 1);
         Y_ = std::vector<DBuf<T>>(M + 1);
-        for (int i = 0; i <= M; ++i) { S_[i].alloc(n); Y_[i].alloc(n); }
+        for (int i = 0; i <= M; ++i) { S_[i].alloc(vcap); Y_[i].alloc(vcap); }
     }
     void lbfgs_reset_all() {
         order.clear(); freeslots.clear();
@@ -604,13 +624,18 @@ template <class T> class Solver final : public SolverBase {
         a.counter = pcounter_.p; a.base = pbase; a.timeout = ptimeout_dev_;
         a.slot_loop1 = SL_LOOP1; a.slot_loop2 = SL_LOOP2;
         pbase += (unsigned long long)(2 * m - 1) * num_cus;
-        const int64_t nchunks = (n + PackN<T>::N - 1) / PackN<T>::N;
-        const int64_t kneed = (nchunks + (int64_t)num_cus * PBLOCK - 1) / ((int64_t)num_cus * PBLOCK);
-        if (kneed <= 8) launch_persist(k_twoloop_persist<T, 8>, a);
-        else if (kneed <= 16) launch_persist(k_twoloop_persist<T, 16>, a);
-        else if (kneed <= 24) launch_persist(k_twoloop_persist<T, 24>, a);
-        else if (kneed <= 32) launch_persist(k_twoloop_persist<T, 32>, a);
-        else launch_persist(k_twoloop_persist<T, 40>, a);
+        switch (persist_kr) {
+        case 4: launch_persist(k_twoloop_persist<T, 4>, a); break;
+        case 8: launch_persist(k_twoloop_persist<T, 8>, a); break;
+        case 12: launch_persist(k_twoloop_persist<T, 12>, a); break;
+        case 16: launch_persist(k_twoloop_persist<T, 16>, a); break;
+        case 20: launch_persist(k_twoloop_persist<T, 20>, a); break;
+        case 24: launch_persist(k_twoloop_persist<T, 24>, a); break;
+        case 28: launch_persist(k_twoloop_persist<T, 28>, a); break;
+        case 32: launch_persist(k_twoloop_persist<T, 32>, a); break;
+        case 36: launch_persist(k_twoloop_persist<T, 36>, a); break;
+        default: launch_persist(k_twoloop_persist<T, 40>, a); break;
+        }
         slot_n[SL_LOOP2 + 0] = num_cus;
         t.in = D_.p; t.sgn = T(1); t.v = S_[order[0]].p; t.mode = 1; t.j = 0; t.apply_H = 0; t.H = T(1);
         t.src = src(SL_LOOP2 + 0); t.ys = ys_[order[0]];
@@ -689,11 +714,9 @@ template <class T> class Solver final : public SolverBase {
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
             // block per CU) and the vector must be long enough for 2m-1 grid barriers to beat 2m launches
-            const int64_t nchunks = (n + PackN<T>::N - 1) / PackN<T>::N;
-            const int64_t kneed = (nchunks + (int64_t)num_cus * PBLOCK - 1) / ((int64_t)num_cus * PBLOCK);
             int64_t min_n = 2000000;
             if (const char* e = getenv("BZ_PERSIST_MIN_N")) min_n = atoll(e);
-            persist_ok = o.persist && !ctx->comm && num_cus > 0 && num_cus <= PSTRIDE && kneed <= 40 && n >= min_n;
+            persist_ok = o.persist && !ctx->comm && persist_kr > 0 && n >= min_n;
         }
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;

@@ -222,7 +222,7 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
 /* category: 0 k_axpy_dot (two-loop step), 1 k_fused_sep (fused separable iteration),
  *           2 AL gradient, 3 forward-backward step, 4 L-BFGS update/stop norm,
  *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot),
- *           9 dense GEMV kernels, 10 k_twoloop_persist.
+ *           9 dense GEMV kernels (vector ALU), 10 k_twoloop_persist, 11 k_gemv_t_mfma.
  * mask: bit c enables timing of category c (0 = off, -1 = all).                     */
 #define BZ_NUM_KERNEL_CATEGORIES 12
 int bz_profile_enable(bz_problem* p, int32_t mask);

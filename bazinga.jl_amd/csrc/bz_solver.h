@@ -56,7 +56,10 @@ template <class T> struct DBuf {
         n = count;
         if (count) {
             BZ_HIP(hipMalloc((void**)&p, (count + 8) * sizeof(T)));
-            BZ_HIP(hipMemset(p, 0, (count + 8) * sizeof(T)));
+            // hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which
+            // the solver's non-blocking stream does not wait for: drain it before anyone uses the buffer
+            BZ_HIP(hipMemsetAsync(p, 0, (count + 8) * sizeof(T), nullptr));
+            BZ_HIP(hipStreamSynchronize(nullptr));
         }
     }
     void release() {

@@ -348,26 +348,45 @@ k_dot(const T* __restrict__ a, const T* __restrict__ b, T sgn, int64_t n,
 // K1: AL gradient, element-wise kinds (c = Identity; f = Zero | DiagQuadratic)
 //   slots: +0 sum f terms, +1 sum t^2/mu
 // ---------------------------------------------------------------------------
+// fext (dense f evaluated by the GEMV kernels, ProximalOperators LeastSquares / Quadratic):
+//   0: f element-wise as given by P.f_kind
+//   1: dfx = ext[i], f value comes from another kernel -> only the penalty slot (+1) is written
+//   2: ext = Q x ; dfx = ext + P.b (b holds q) ; fterm = x (0.5 ext + q)
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, int64_t n,
-              double* __restrict__ parts, int slot0) {
+              double* __restrict__ parts, int slot0, int fext, const T* __restrict__ ext) {
     double acc[2] = {0.0, 0.0};
+    const int fk = fext ? BZ_F_ZERO : P.f_kind;
     BZ_FOR_EACH_CHUNK(T, n) {
         BZ_CHUNK_VARS(T, n)
         ElemLoads<T> L;
-        load_params(P, i0, cnt, L, true, true, false);
+        load_params(P, i0, cnt, L, fext == 0, true, false);
         Pack<T> px = ld(x, i0, cnt), pg;
+        Pack<T> pe = fext ? ld(ext, i0, cnt) : splat(T(0));
+        Pack<T> pq = (fext == 2) ? ld(P.b, i0, cnt) : splat(T(0));
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
-            ALOut<T> o = al_elem(P.f_kind, P.D_kind, px.v[e], L.q.v[e], L.b.v[e], L.mu.v[e],
+            ALOut<T> o = al_elem(fk, P.D_kind, px.v[e], L.q.v[e], L.b.v[e], L.mu.v[e],
                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+            if (fext == 1) {
+                o.grad = pe.v[e] + o.grad;                   // dfx + yupd  (al_elem returned 0 + yupd)
+            } else if (fext == 2) {
+                const T dfx = pe.v[e] + pq.v[e];
+                o.fterm = px.v[e] * (T(0.5) * pe.v[e] + pq.v[e]);
+                o.grad = dfx + o.grad;
+            }
             pg.v[e] = o.grad;
             if (e < cnt) { acc[0] += (double)o.fterm; acc[1] += (double)o.pterm; }
         }
         if (grad) st(grad, i0, cnt, pg);
     }
-    block_reduce_store<2>(acc, 0u, parts, slot0);
+    if (fext == 1) {
+        double a1[1] = {acc[1]};
+        block_reduce_store<1>(a1, 0u, parts, slot0 + 1);
+    } else {
+        block_reduce_store<2>(acc, 0u, parts, slot0);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -438,11 +457,14 @@ k_gemv_n(const T* __restrict__ A, const T* __restrict__ p, const T* __restrict__
          T* __restrict__ cx, int64_t ny, int64_t n) {
     constexpr int N = PackN<T>::N;
     __shared__ double sh[WAVES];
-    const int64_t npk = n / N;              // host guarantees n % N == 0
+    const bool aligned = (n % N) == 0;      // rows start 16-B aligned only then
+    const int64_t npk = aligned ? n / N : 0;
     for (int64_t r = blockIdx.x; r < ny; r += gridDim.x) {
         const T* row = A + r * n;
         T a0 = T(0), a1 = T(0);
         int64_t c = threadIdx.x;
+        if (!aligned)
+            for (int64_t j = threadIdx.x; j < n; j += BLOCK) a0 += row[j] * p[j];
         for (; c + BLOCK < npk; c += 2 * BLOCK) {
             Pack<T> ra = *reinterpret_cast<const Pack<T>*>(row + c * N);
             Pack<T> rb = *reinterpret_cast<const Pack<T>*>(row + (c + BLOCK) * N);
@@ -462,7 +484,7 @@ k_gemv_n(const T* __restrict__ A, const T* __restrict__ p, const T* __restrict__
         __syncthreads();
         if (threadIdx.x == 0) {
             T dot = (T)((sh[0] + sh[1]) + (sh[2] + sh[3]));
-            cx[r] = dot - b[r];
+            cx[r] = b ? dot - b[r] : dot;
         }
         __syncthreads();
     }
@@ -499,12 +521,20 @@ k_yupd(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ yupd, int64_t 
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_gemv_t(const T* __restrict__ A, const T* __restrict__ v, T* __restrict__ part, int64_t ny,
-         int64_t n, int rows_per_chunk) {
+         int64_t n, int rows_per_chunk, int64_t pstride) {
     constexpr int N = PackN<T>::N;
     const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;     // pack index along the row
-    if (c * N >= n) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = (r0 + rows_per_chunk < ny) ? r0 + rows_per_chunk : ny;
+    if ((n % N) != 0) {                     // rows not 16-B aligned: one column per thread
+        if (c < n) {
+            T a = T(0);
+            for (int64_t r = r0; r < r1; ++r) a += A[r * n + c] * v[r];
+            part[(int64_t)blockIdx.y * pstride + c] = a;
+        }
+        return;
+    }
+    if (c * N >= n) return;
     Pack<T> a0 = splat(T(0)), a1 = splat(T(0));
     const T* col = A + c * N;
     int64_t r = r0;
@@ -524,7 +554,7 @@ k_gemv_t(const T* __restrict__ A, const T* __restrict__ v, T* __restrict__ part,
     Pack<T> o;
 #pragma unroll
     for (int e = 0; e < N; ++e) o.v[e] = a0.v[e] + a1.v[e];
-    *reinterpret_cast<Pack<T>*>(part + (int64_t)blockIdx.y * n + c * N) = o;
+    *reinterpret_cast<Pack<T>*>(part + (int64_t)blockIdx.y * pstride + c * N) = o;
 }
 
 // jtv partials on the matrix cores (fp32): v_mfma_f32_16x16x4_f32 with the matrix tile as the B
@@ -539,7 +569,7 @@ typedef float bz_f32x4 __attribute__((ext_vector_type(4)));
 
 static __global__ void __launch_bounds__(BLOCK)
 k_gemv_t_mfma(const float* __restrict__ A, const float* __restrict__ v, float* __restrict__ part,
-              int64_t ny, int64_t n, int rows_per_chunk) {
+              int64_t ny, int64_t n, int rows_per_chunk, int64_t pstride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j0 = ((int64_t)blockIdx.x * WAVES + wave) * 64;      // 64 columns per wave
     if (j0 >= n) return;                                              // wave-uniform
@@ -576,7 +606,7 @@ k_gemv_t_mfma(const float* __restrict__ A, const float* __restrict__ v, float* _
     if (lane < 16) {                                                  // D row 0 = lanes 0..15, register 0
         Pack<float> o;
         o.v[0] = acc0[0]; o.v[1] = acc1[0]; o.v[2] = acc2[0]; o.v[3] = acc3[0];
-        *reinterpret_cast<Pack<float>*>(part + (int64_t)blockIdx.y * n + j0 + 4 * lane) = o;
+        *reinterpret_cast<Pack<float>*>(part + (int64_t)blockIdx.y * pstride + j0 + 4 * lane) = o;
     }
 }
 
@@ -584,14 +614,14 @@ k_gemv_t_mfma(const float* __restrict__ A, const float* __restrict__ v, float* _
 //   slot +0: sum f terms
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
-k_gemv_t_finish(const T* __restrict__ part, int nchunks, const T* __restrict__ x, ElemParams<T> P,
-                T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
+k_gemv_t_finish(const T* __restrict__ part, int nchunks, int64_t pstride, const T* __restrict__ x,
+                ElemParams<T> P, T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
     double acc[1] = {0.0};
     BZ_FOR_EACH_CHUNK(T, n) {
         BZ_CHUNK_VARS(T, n)
         Pack<T> j = ld(part, i0, cnt);
         for (int k = 1; k < nchunks; ++k) {
-            Pack<T> q = ld(part + (int64_t)k * n, i0, cnt);
+            Pack<T> q = ld(part + (int64_t)k * pstride, i0, cnt);
 #pragma unroll
             for (int e = 0; e < PackN<T>::N; ++e) j.v[e] = j.v[e] + q.v[e];
         }
@@ -1161,19 +1191,23 @@ k_absmax(const T* __restrict__ v, int64_t n, double* __restrict__ parts, int slo
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_fvalue_elem(const T* __restrict__ x, ElemParams<T> P, int64_t n, double* __restrict__ parts,
-              int slot0) {
+              int slot0, const T* __restrict__ ext) {
     double acc[1] = {0.0};
     BZ_FOR_EACH_CHUNK(T, n) {
         BZ_CHUNK_VARS(T, n)
         Pack<T> px = ld(x, i0, cnt);
         Pack<T> q = splat(T(0)), b = splat(T(0));
         if (P.f_kind == BZ_F_DIAG_QUADRATIC) { q = ld(P.q, i0, cnt); b = ld(P.b, i0, cnt); }
+        if (ext) { q = ld(ext, i0, cnt); b = ld(P.b, i0, cnt); }      // dense Quadratic: q := Q x, b := q
 #pragma unroll
-        for (int e = 0; e < PackN<T>::N; ++e)
-            if (e < cnt && P.f_kind == BZ_F_DIAG_QUADRATIC) {
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            if (e < cnt && ext) {
+                acc[0] += (double)(px.v[e] * (T(0.5) * q.v[e] + b.v[e]));
+            } else if (e < cnt && P.f_kind == BZ_F_DIAG_QUADRATIC) {
                 T qx = q.v[e] * px.v[e];
                 acc[0] += (double)(px.v[e] * (T(0.5) * qx - b.v[e]));
             }
+        }
     }
     block_reduce_store<1>(acc, 0u, parts, slot0);
 }

@@ -78,7 +78,8 @@ enum Slot : int {
     SL_FZ = 37, SL_PZ = 38, SL_YS = 39, SL_YTY = 40, SL_STOP = 41,
     SL_AUX = 42,       // 2 slots: Lipschitz estimate / misc
     SL_OUTER = 44,     // 2 slots: outer loop
-    SL_COUNT = 46
+    SL_SCRATCH = 46,   // sink for partials nobody reads
+    SL_COUNT = 47
 };
 constexpr int MAX_MEM = 16;
 

@@ -58,13 +58,19 @@ template <class T> class Solver final : public SolverBase {
             throw Error(BZ_ERR_UNSUPPORTED, "constraint kind not lowered to the device");
         if (d.c_kind == BZ_C_DENSE_AFFINE) {
             if (ny <= 0 || !d.c_A || !d.c_b) throw Error(BZ_ERR_ARG, "DenseAffine needs A[ny][n] and b[ny]");
-            if (n % PackN<T>::N != 0) throw Error(BZ_ERR_ARG, "DenseAffine: n must be a multiple of 16 bytes");
             if (d.f_kind == BZ_F_STENCIL5) throw Error(BZ_ERR_UNSUPPORTED, "Stencil5pt f with a dense c");
             if (ctx->nranks > 1)
                 throw Error(BZ_ERR_UNSUPPORTED, "DenseAffine is not sharded (needs an n-vector all-reduce)");
         }
-        if (d.f_kind != BZ_F_ZERO && d.f_kind != BZ_F_DIAG_QUADRATIC && d.f_kind != BZ_F_STENCIL5)
+        if (d.f_kind < BZ_F_ZERO || d.f_kind > BZ_F_QUADRATIC)
             throw Error(BZ_ERR_UNSUPPORTED, "smooth-cost kind not lowered to the device");
+        dense_f = d.f_kind == BZ_F_LEAST_SQUARES || d.f_kind == BZ_F_QUADRATIC;
+        if (dense_f) {
+            if (!d.f_A || !d.f_b || d.f_rows <= 0) throw Error(BZ_ERR_ARG, "dense f needs its matrix, vector and row count");
+            if (d.f_kind == BZ_F_QUADRATIC && d.f_rows != n) throw Error(BZ_ERR_ARG, "Quadratic: Q must be n-by-n");
+            if (d.c_kind != BZ_C_IDENTITY) throw Error(BZ_ERR_UNSUPPORTED, "dense f with a dense c");
+            if (ctx->nranks > 1) throw Error(BZ_ERR_UNSUPPORTED, "dense f is not sharded");
+        }
         if (d.f_kind == BZ_F_STENCIL5) {
             if (d.f_grid_nx <= 0 || d.f_grid_ny <= 0 || d.f_grid_nx * d.f_grid_ny != n)
                 throw Error(BZ_ERR_ARG, "Stencil5pt: grid nx*ny must equal n");
@@ -98,17 +104,30 @@ template <class T> class Solver final : public SolverBase {
         const int64_t nychunks = (ny + PackN<T>::N - 1) / PackN<T>::N;
         grid_y = (int)std::min<int64_t>(grid, std::max<int64_t>(1, (nychunks + BLOCK - 1) / BLOCK));
         if (d.c_kind == BZ_C_IDENTITY) grid_y = grid;
+        npad = ((n + PackN<T>::N - 1) / PackN<T>::N) * PackN<T>::N;
+        if (dense_f) {
+            frows = d.f_rows;
+            FA_.alloc((size_t)frows * n);
+            BZ_HIP(hipMemcpyAsync(FA_.p, d.f_A, (size_t)frows * n * sizeof(T), hipMemcpyDefault, ctx->stream));
+            BZ_HIP(hipStreamSynchronize(ctx->stream));
+            upload(fb_, d.f_b, d.f_kind == BZ_F_LEAST_SQUARES ? frows : n);
+            FR_.alloc(std::max<int64_t>(frows, n));
+            P.b = fb_.p;                                   // Quadratic: q (read by the element-wise kernels)
+            fscale = d.f_kind == BZ_F_LEAST_SQUARES ? T(0.5) : T(1);
+            if (d.f_kind == BZ_F_LEAST_SQUARES) {
+                DFX_.alloc(npad);
+                plan_chunks(frows, f_rows_per_chunk, f_nrowchunks);
+                GT_.alloc((size_t)f_nrowchunks * npad);
+            }
+        }
         if (d.c_kind == BZ_C_DENSE_AFFINE) {
             A_.alloc((size_t)ny * n);
             BZ_HIP(hipMemcpyAsync(A_.p, d.c_A, (size_t)ny * n * sizeof(T), hipMemcpyDefault, ctx->stream));
             BZ_HIP(hipStreamSynchronize(ctx->stream));
             upload(cb_, d.c_b, ny);
             CX_.alloc(ny); YU_.alloc(ny);
-            const int64_t colblocks = (n / PackN<T>::N + BLOCK - 1) / BLOCK;
-            int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ny, (2048 + colblocks - 1) / colblocks));
-            rows_per_chunk = (int)((ny + chunks - 1) / chunks);
-            nrowchunks = (int)((ny + rows_per_chunk - 1) / rows_per_chunk);
-            GT_.alloc((size_t)nrowchunks * n);
+            plan_chunks(ny, rows_per_chunk, nrowchunks);
+            GT_.alloc((size_t)nrowchunks * npad);
         }
 
         std::memset(&P, 0, sizeof(P));
@@ -228,7 +247,7 @@ template <class T> class Solver final : public SolverBase {
         auto v = collect({SL_AUX, SL_AUX + 1}, 0u);
         T half_pen = T(0.5) * T(v[1]);
         vals3[0] = (double)al_value(v[0], v[1]);
-        vals3[1] = (double)T(v[0]);
+        vals3[1] = (double)f_value(v[0]);
         vals3[2] = (double)half_pen;
         if (dlx) copy_out(dlx, D_.p, n);
     }
@@ -299,7 +318,7 @@ template <class T> class Solver final : public SolverBase {
         fvalue(x, SL_AUX);
         auto v0 = collect({SL_GSUM, SL_AUX}, 0u);
         T gz0 = g_value(v0[0]);
-        T objx = T(v0[1]) + gz0;
+        T objx = f_value(v0[1]) + gz0;
         // eval!(cx,c,x); proj!(s,D,cx); default_penalty_parameter!     alps.jl:40-42
         const double denom = std::max(1.0, (double)objx);
         const bool dense_c = desc.c_kind == BZ_C_DENSE_AFFINE;
@@ -380,6 +399,11 @@ template <class T> class Solver final : public SolverBase {
     DBuf<T> X_[3], RES_[2], Z_[2], GX_, GZ_, D_, TMP_;
     DBuf<T> A_, cb_, CX_, YU_, GT_;          // DenseAffine c: A[ny][n], b, c(x), yupd, A'v row-chunk partials
     int rows_per_chunk = 1, nrowchunks = 1;
+    DBuf<T> FA_, fb_, FR_, DFX_;             // dense f: matrix, vector, residual / Qx, gradient of f
+    bool dense_f = false;
+    int64_t frows = 0, npad = 0;
+    int f_rows_per_chunk = 1, f_nrowchunks = 1;
+    T fscale = T(1);                         // f(x) = fscale * (sum of the f partials)
     // persistent two-loop
     DBuf<unsigned long long> pcounter_;
     unsigned long long pbase = 0;
@@ -515,10 +539,11 @@ template <class T> class Solver final : public SolverBase {
 
     T al_value(double fsum, double pensum) const {   // auglagfun.jl:78,81-82
         T lx = T(0.5) * T(pensum);
-        lx += T(fsum);
+        lx += f_value(fsum);
         lx -= musqy;
         return lx;
     }
+    T f_value(double fsum) const { return fscale == T(1) ? T(fsum) : fscale * T(fsum); }
     T g_value(double gsum) const {
         switch (desc.g_kind) {
         case BZ_G_NORM_L1: case BZ_G_NORM_L1_NONNEG: case BZ_G_NORM_L1_BOX:
@@ -528,48 +553,91 @@ template <class T> class Solver final : public SolverBase {
     }
 
     // gradient!(dlx, al, x) on the device; partials -> slot0 (f terms), slot0+1 (t^2/mu)
-    // eval!(cx, c, x) for the dense constraint
-    void eval_c(const T* x) {
-        launch(C_GEMV, k_gemv_n<T>, (int)std::min<int64_t>(ny, 65535), (const T*)A_.p, x, (const T*)cb_.p, CX_.p, ny, n);
+    // row chunks of the transposed product: enough blocks to fill the chip, fixed summation order
+    void plan_chunks(int64_t rows, int& rpc, int& nch) const {
+        const int64_t colblocks = std::max<int64_t>(1, (n / PackN<T>::N + BLOCK - 1) / BLOCK);
+        const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(rows, (2048 + colblocks - 1) / colblocks));
+        rpc = (int)((rows + chunks - 1) / chunks);
+        nch = (int)((rows + rpc - 1) / rpc);
     }
-    // jtprod!(jtv, c, x, yupd): fp32 with n % 64 == 0 runs on the matrix cores (v_mfma_f32_16x16x4_f32),
-    // everything else on the vector ALUs; both are bound by the bytes of A.
-    void gemv_t() {
+    // out = M p - b (b may be null): M[rows][n] row-major
+    void gemv_rows(const T* M, int64_t rows, const T* p, const T* b, T* out) {
+        launch(C_GEMV, k_gemv_n<T>, (int)std::min<int64_t>(rows, 65535), M, p, b, out, rows, n);
+    }
+    // GT_ partials of M' v over row chunks.  fp32 with n % 64 == 0 runs on the matrix cores
+    // (v_mfma_f32_16x16x4_f32), everything else on the vector ALUs; both are bound by the bytes of M.
+    void gemv_cols(const T* M, int64_t rows, const T* v, int rpc, int nch) {
         if constexpr (std::is_same<T, float>::value) {
             if (n % 64 == 0 && !getenv("BZ_GEMV_VALU")) {
-                launch2d(C_GEMV_MFMA, k_gemv_t_mfma, (int)((n / 64 + WAVES - 1) / WAVES), nrowchunks,
-                         (const float*)A_.p, (const float*)YU_.p, (float*)GT_.p, ny, n, rows_per_chunk);
+                launch2d(C_GEMV_MFMA, k_gemv_t_mfma, (int)((n / 64 + WAVES - 1) / WAVES), nch, (const float*)M,
+                         (const float*)v, (float*)GT_.p, rows, n, rpc, npad);
                 return;
             }
         }
-        const int colblocks = (int)((n / PackN<T>::N + BLOCK - 1) / BLOCK);
-        launch2d(C_GEMV, k_gemv_t<T>, colblocks, nrowchunks, (const T*)A_.p, (const T*)YU_.p, GT_.p, ny, n,
-                 rows_per_chunk);
+        const bool aligned = (n % PackN<T>::N) == 0;
+        const int colblocks = (int)(((aligned ? n / PackN<T>::N : n) + BLOCK - 1) / BLOCK);
+        launch2d(C_GEMV, k_gemv_t<T>, colblocks, nch, M, v, GT_.p, rows, n, rpc, npad);
+    }
+    // eval!(cx, c, x) for the dense constraint
+    void eval_c(const T* x) { gemv_rows(A_.p, ny, x, cb_.p, CX_.p); }
+    // dense f: leaves what k_algrad_elem / k_fvalue_elem need in FR_ / DFX_ and the f partials in slot0
+    //   LeastSquares: r = A x - b ; slot0 <- <r,r> ; DFX = A' r        (ProximalOperators: 0.5||Ax-b||^2)
+    //   Quadratic:    FR = Q x (value and gradient finished element-wise)
+    void dense_f_eval(const T* x, int slot0, bool need_grad) {
+        if (desc.f_kind == BZ_F_LEAST_SQUARES) {
+            gemv_rows(FA_.p, frows, x, fb_.p, FR_.p);
+            const int gm = (int)std::min<int64_t>(grid, std::max<int64_t>(1, (frows / PackN<T>::N + BLOCK) / BLOCK));
+            launch(C_MISC, k_dot<T>, gm, (const T*)FR_.p, (const T*)FR_.p, T(1), frows, parts_.p, slot0);
+            slot_n[slot0] = gm;
+            if (need_grad) {
+                gemv_cols(FA_.p, frows, FR_.p, f_rows_per_chunk, f_nrowchunks);
+                ElemParams<T> Pz = P;
+                Pz.f_kind = BZ_F_ZERO;
+                launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, f_nrowchunks, npad, x, Pz, DFX_.p, n,
+                       parts_.p, (int)SL_SCRATCH);
+            }
+        } else {
+            gemv_rows(FA_.p, n, x, (const T*)nullptr, FR_.p);
+        }
     }
     void algrad(const T* x, T* grad, int slot0) {
         if (desc.c_kind == BZ_C_DENSE_AFFINE) {
             eval_c(x);                                                        // cx = A x - b
             launch(C_MISC, k_yupd<T>, grid_y, (const T*)CX_.p, P, YU_.p, ny, parts_.p, slot0 + 1);
             slot_n[slot0] = grid; slot_n[slot0 + 1] = grid_y;
-            gemv_t();                                                         // jtv = A' yupd (row-chunk partials)
-            launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, x, P, grad, n, parts_.p, slot0);
+            gemv_cols(A_.p, ny, YU_.p, rows_per_chunk, nrowchunks);           // jtv = A' yupd (row-chunk partials)
+            launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, npad, x, P, grad, n, parts_.p, slot0);
             gather(slot0, 2, 0u);
             return;
         }
-        if (desc.f_kind == BZ_F_STENCIL5)
+        slot_n[slot0] = slot_n[slot0 + 1] = grid;
+        if (dense_f) {
+            dense_f_eval(x, slot0, true);
+            if (desc.f_kind == BZ_F_LEAST_SQUARES)
+                launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 1, (const T*)DFX_.p);
+            else
+                launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 2, (const T*)FR_.p);
+        } else if (desc.f_kind == BZ_F_STENCIL5) {
             launch(C_ALGRAD, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 0,
                    grad, n, parts_.p, slot0);
-        else
-            launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0);
+        } else {
+            launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 0, (const T*)nullptr);
+        }
         gather(slot0, 2, 0u);
     }
     // f(x) alone (alps.jl:39): partial sums -> slot0
     void fvalue(const T* x, int slot0) {
-        if (desc.f_kind == BZ_F_STENCIL5)
+        slot_n[slot0] = grid;
+        if (dense_f) {
+            dense_f_eval(x, slot0, false);
+            if (desc.f_kind == BZ_F_QUADRATIC)
+                launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0, (const T*)FR_.p);
+        } else if (desc.f_kind == BZ_F_STENCIL5) {
             launch(C_MISC, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 1,
                    (T*)nullptr, n, parts_.p, slot0);
-        else
-            launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0);
+        } else {
+            launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0, (const T*)nullptr);
+        }
         gather(slot0, 1, 0u);
     }
 
@@ -751,7 +819,7 @@ template <class T> class Solver final : public SolverBase {
             algrad(Z_[zc].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
             auto v = collect({SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ}, 0u);
             g_z = g_value(v[0]); dot_gr = T(v[1]); ss_res = T(v[2]);
-            f_z = al_value(v[3], v[4]); fraw_last = T(v[3]); f_z_al = f_z;
+            f_z = al_value(v[3], v[4]); fraw_last = f_value(v[3]); f_z_al = f_z;
             const T nr = std::sqrt(ss_res);
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));
@@ -845,7 +913,7 @@ template <class T> class Solver final : public SolverBase {
             f_x = al_value(v[0], v[1]);
             g_z = g_value(v[2]); dot_gr = T(v[3]); ss_res = T(v[4]);
             const T f_z = al_value(v[5], v[6]);
-            fraw_last = T(v[5]); f_z_al = f_z;
+            fraw_last = f_value(v[5]); f_z_al = f_z;
             const T nr = std::sqrt(ss_res);
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));

@@ -46,6 +46,27 @@ class DiagQuadratic(ProximableFunction):
             raise ValueError("q and b must be vectors of equal length")
 
 
+class LeastSquares(ProximableFunction):
+    """ProximalOperators.LeastSquares(A, b): f(x) = 0.5||A x - b||^2 (test/problems/test_verbose.jl:22)."""
+
+    def __init__(self, A, b):
+        self.A = np.ascontiguousarray(A)
+        self.b = np.ascontiguousarray(b)
+        if self.A.ndim != 2 or self.b.shape != (self.A.shape[0],):
+            raise ValueError("A must be m-by-n and b of length m")
+
+
+class Quadratic(ProximableFunction):
+    """ProximalOperators.Quadratic(Q, q): f(x) = 0.5 x'Qx + q'x, Q dense symmetric
+    (test/problems/test_nonconvex_qp.jl:14,65)."""
+
+    def __init__(self, Q, q):
+        self.Q = np.ascontiguousarray(Q)
+        self.q = np.ascontiguousarray(q)
+        if self.Q.ndim != 2 or self.Q.shape[0] != self.Q.shape[1] or self.q.shape != (self.Q.shape[0],):
+            raise ValueError("Q must be n-by-n and q of length n")
+
+
 class Stencil5ptQuadratic(ProximableFunction):
     """f(x) = 0.5 x'A_h x - b'x on an nx-by-ny grid (row-major), A_h the 5-point Laplacian
     (4,-1,-1,-1,-1) with homogeneous Dirichlet halo — the structured `Quadratic` of BASELINE
@@ -172,6 +193,20 @@ def lower(f, g, c, D, n, ny, dtype):
         d.f_kind = L.BZ_F_DIAG_QUADRATIC
         d.f_q = ptr(_vec(f.q, dtype, n, "q"))
         d.f_b = ptr(_vec(f.b, dtype, n, "b"))
+    elif isinstance(f, LeastSquares):
+        d.f_kind = L.BZ_F_LEAST_SQUARES
+        if f.A.shape[1] != n:
+            raise ValueError(f"A must have {n} columns")
+        d.f_A = ptr(np.ascontiguousarray(f.A, dtype=dtype))
+        d.f_rows = f.A.shape[0]
+        d.f_b = ptr(_vec(f.b, dtype, f.A.shape[0], "b"))
+    elif isinstance(f, Quadratic):
+        d.f_kind = L.BZ_F_QUADRATIC
+        if f.Q.shape != (n, n):
+            raise ValueError(f"Q must be {n}-by-{n}")
+        d.f_A = ptr(np.ascontiguousarray(f.Q, dtype=dtype))
+        d.f_rows = n
+        d.f_b = ptr(_vec(f.q, dtype, n, "q"))
     elif isinstance(f, Stencil5ptQuadratic):
         d.f_kind = L.BZ_F_STENCIL5
         d.f_grid_nx, d.f_grid_ny = f.nx, f.ny

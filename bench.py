@@ -174,10 +174,10 @@ def main():
 
     for _ in range(args.warmup):
         prob.panoc_step()
-    # HIP events (recorded by the library on ITS stream) around every launch of the dominant kernel
-    cat = bz._lib.KERNEL_CATEGORIES.index("k_axpy_dot")
+    # HIP events bound to each dispatch on the library's own stream (hipExtLaunchKernelGGL start/stop
+    # events): per-kernel durations over the timed region.  Steady state is 3 launches per iteration.
     prob.profile_reset()
-    prob.profile_enable(1 << cat)
+    prob.profile_enable(True)
     st0 = prob.panoc_stats()
     barrier()
     t0 = time.perf_counter()
@@ -192,7 +192,7 @@ def main():
         elapsed = float(t.item())
     st1 = prob.panoc_stats()
     sc = prob.panoc_scalars()
-    prof = prob.profile()["k_axpy_dot"]
+    prof_all = prob.profile()
 
     if rank == 0:
         its = args.steps / elapsed
@@ -200,19 +200,29 @@ def main():
         n_al = (st1.n_grad - st0.n_grad) / args.steps
         n_fb = (st1.n_prox - st0.n_prox) / args.steps
         m = int(sc["lbfgs_mem"])
-        # dominant kernel: k_axpy_dot = one step of the L-BFGS two-loop (d = +-d + coef*v, then <w,d>).
-        # per iteration at m = 5: 8 launches of 3R+1W and the middle one (v == w) 2R+1W over the
-        # local shard -> algorithmic bytes per launch = (35/9) * 8 * n_local
+        w = 8
+        # dominant kernel = largest total time in the timed region.  ALGORITHMIC bytes per launch follow
+        # SURVEY.md §8(d) (compulsory passes under the reference's dataflow), over the local shard:
+        #   k_twoloop_persist : the two-loop minus its last axpy = (8m+1) - 4 passes      (moves 4m)
+        #   k_axpy_dot        : 3R+1W per step, the middle step 2R+1W -> (8m-5)/(2m-1) passes on average
+        #   k_fused_sep       : last axpy + x_d (4) + 2 AL gradients (2*6) + FB step (4) + update/stop (8)
+        alg_passes = {"k_twoloop_persist": (8 * m + 1) - 4,
+                      "k_axpy_dot": (4.0 * (2 * m - 2) + 3.0) / (2 * m - 1) if m >= 1 else 0.0,
+                      "k_fused_sep": 4 + 12 + 4 + 8}
+        cands = {k: v for k, v in prof_all.items() if k in alg_passes and v["launches"]}
+        dom = max(cands, key=lambda k: cands[k]["total_ms"])
+        prof = cands[dom]
         launches_per_it = prof["launches"] / max(1, args.steps)
-        passes = (4.0 * (2 * m - 2) + 3.0) / (2 * m - 1) if m >= 1 else 0.0
-        bytes_per_launch = passes * 8 * nl
+        bytes_per_launch = alg_passes[dom] * w * nl
         avg_s = (prof["total_ms"] / 1e3) / max(1, prof["launches"])
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_k_axpy_dot.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
         if os.path.exists(pmc) and world == 1 and n == 10_000_000:
             with open(pmc) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
+                pj = json.load(fh)
+            if pj.get("kernel") == dom:
+                traffic = pj.get("hbm_bytes_per_launch")
         b_iter = algorithmic_bytes_per_iter(n, n_al=2, n_fb=1)
         out = {
             "metric": "PANOC inner iterations/sec, n=10^7 l1-quadratic" if n == 10_000_000 else "PANOC inner iterations/sec, n=%d l1-quadratic" % n,
@@ -226,8 +236,12 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"x sharded over {world} GPUs, scalar all-gather"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "bz::k_axpy_dot<double>", "launches_per_iteration": round(launches_per_it, 2),
-                         "avg_launch_us": round(avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+                         "kernel": "bz::%s<double>" % dom, "launches_per_iteration": round(launches_per_it, 2),
+                         "avg_launch_us": round(avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "algorithmic_passes_per_launch": round(alg_passes[dom], 3)},
+            "kernels": {k: {"launches_per_iteration": round(v["launches"] / args.steps, 2),
+                            "avg_us": round(1e3 * v["total_ms"] / v["launches"], 2)}
+                        for k, v in prof_all.items() if v["launches"]},
             "roofline_iteration": {"algorithmic_bytes_per_iteration": b_iter,
                                    "achieved": round(b_iter * its / 1e9, 1), "unit": "GB/s",
                                    "frac": round(b_iter * its / 1e9 / HBM_PEAK_GBS, 4),

@@ -49,6 +49,10 @@ extern "C" {
 #define BZ_F_DIAG_QUADRATIC  1   /* sum x_i(0.5 q_i x_i - b_i): diagonal case of
                                     ProximalOperators.Quadratic (test_nonconvex_qp.jl:14) */
 #define BZ_F_STENCIL5        2   /* 0.5 x'A_h x - b'x, A_h = 5-pt Laplacian, Dirichlet */
+#define BZ_F_LEAST_SQUARES   3   /* 0.5||A x - b||^2, ProximalOperators.LeastSquares
+                                    (test/problems/test_verbose.jl:22)                 */
+#define BZ_F_QUADRATIC       4   /* 0.5 x'Qx + q'x, dense symmetric Q, ProximalOperators.
+                                    Quadratic (test/problems/test_nonconvex_qp.jl:14)  */
 /* g: proximable cost.  prox!(z,g,x,gamma)->g(z)                                     */
 #define BZ_G_ZERO            0   /* zero.jl:22-25, ProximalOperators.Zero / IndFree   */
 #define BZ_G_NORM_L1         1   /* ProximalOperators.NormL1(lambda) (test_verbose.jl:23) */
@@ -97,6 +101,9 @@ typedef struct {
     const void* f_q;               /* DIAG_QUADRATIC: q[n]                            */
     const void* f_b;               /* DIAG_QUADRATIC / STENCIL5: b[n]                 */
     int64_t     f_grid_nx, f_grid_ny; /* STENCIL5: grid rows, cols (row-major, n=nx*ny) */
+    const void* f_A;               /* LEAST_SQUARES: A[f_rows][n]; QUADRATIC: Q[n][n]; row-major;
+                                      f_b then holds b[f_rows] resp. q[n]                */
+    int64_t     f_rows;
     /* g */
     double      g_lambda;          /* NORM_L1*: lambda >= 0                           */
     const void* g_u;               /* NORM_L1_BOX: u[n] >= 0                          */

@@ -25,6 +25,7 @@ Base.@kwdef mutable struct ProblemDesc
     data_on_device::Int32 = 0
     n::Int64 = 0; ny::Int64 = 0
     f_q::Ptr{Cvoid} = C_NULL; f_b::Ptr{Cvoid} = C_NULL; f_grid_nx::Int64 = 0; f_grid_ny::Int64 = 0
+    f_A::Ptr{Cvoid} = C_NULL; f_rows::Int64 = 0
     g_lambda::Float64 = 0; g_u::Ptr{Cvoid} = C_NULL; g_lo::Float64 = 0; g_hi::Float64 = 0
     g_lo_vec::Ptr{Cvoid} = C_NULL; g_hi_vec::Ptr{Cvoid} = C_NULL
     c_A::Ptr{Cvoid} = C_NULL; c_b::Ptr{Cvoid} = C_NULL
@@ -69,6 +70,11 @@ dtype_code(::Type{Float32}) = Int32(1)
 lower_f!(d, f::Bazinga.Zero) = (d.f_kind = 0)
 lower_f!(d, f::ProximalOperators.Zero) = (d.f_kind = 0)
 lower_f!(d, f::DiagQuadratic) = (d.f_kind = 1; d.f_q = pointer(f.q); d.f_b = pointer(f.b))
+# dense f: Julia matrices are column-major, the library wants row-major -> pass the transpose's memory
+lower_f!(d, f::ProximalOperators.LeastSquares) = (At = permutedims(f.A); d.f_kind = 3; d.f_A = pointer(At);
+                                                  d.f_rows = size(f.A, 1); d.f_b = pointer(f.b); At)
+lower_f!(d, f::ProximalOperators.Quadratic) = (d.f_kind = 4; d.f_A = pointer(f.Q); d.f_rows = size(f.Q, 1);
+                                               d.f_b = pointer(f.q))      # Q symmetric: layout-agnostic
 lower_f!(d, f) = error("BazingaHIP: f of type $(typeof(f)) is not lowered to the device")
 
 lower_g!(d, g::Bazinga.Zero) = (d.g_kind = 0)

@@ -112,7 +112,6 @@ template <class T> class Solver final : public SolverBase {
             BZ_HIP(hipStreamSynchronize(ctx->stream));
             upload(fb_, d.f_b, d.f_kind == BZ_F_LEAST_SQUARES ? frows : n);
             FR_.alloc(std::max<int64_t>(frows, n));
-            P.b = fb_.p;                                   // Quadratic: q (read by the element-wise kernels)
             fscale = d.f_kind == BZ_F_LEAST_SQUARES ? T(0.5) : T(1);
             if (d.f_kind == BZ_F_LEAST_SQUARES) {
                 DFX_.alloc(npad);
@@ -137,6 +136,7 @@ template <class T> class Solver final : public SolverBase {
             upload(q_, d.f_q, n); upload(b_, d.f_b, n);
             P.q = q_.p; P.b = b_.p;
         }
+        if (dense_f) P.b = fb_.p;                          // Quadratic: q, read by the element-wise kernels
         if (d.f_kind == BZ_F_STENCIL5) {
             if (!d.f_b) throw Error(BZ_ERR_ARG, "Stencil5pt needs b");
             upload(b_, d.f_b, n);

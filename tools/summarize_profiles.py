@@ -23,7 +23,8 @@ def counter_avgs(d, name):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+    # median: the first launches of a solve run with fewer L-BFGS pairs (m < 5) and move fewer bytes
+    return {k: (sorted(v)[len(v) // 2], len(v)) for k, v in agg.items()}
 
 
 def short(k):
@@ -49,7 +50,7 @@ def main(tag="r01"):
     for k in fetch:
         f, nf = fetch[k]
         w, nw = write.get(k, (0.0, 0))
-        summary[short(k)] = {"FETCH_SIZE_KiB_avg": round(f, 1), "WRITE_SIZE_KiB_avg": round(w, 1), "launches_fetch_pass": nf,
+        summary[short(k)] = {"FETCH_SIZE_KiB_median": round(f, 1), "WRITE_SIZE_KiB_median": round(w, 1), "launches_fetch_pass": nf,
                              "launches_write_pass": nw, "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
     with open(os.path.join(out_dir, f"{tag}_pmc_hbm_traffic_n1e7.json"), "w") as fh:
         json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 10 --warmup 5 "

@@ -530,3 +530,103 @@ def test_persistent_kernel_is_used_at_benchmark_size(bz, ref):
     p = prob.profile()
     assert p["k_twoloop_persist"]["launches"] >= 6 and p["k_fused_sep"]["launches"] == 8
     prob.close()
+
+
+# ------------------------------------------------------------------ solver semantics / edge cases
+@pytest.mark.parametrize("tol,maxit", [(1e-2, 1000), (1e-6, 1000), (1e-12, 7), (1e30, 1000), (1e-8, 1)])
+def test_subsolver_return_contract(bz, ref, tol, maxit):
+    """`sol, it = PANOCplus(tol=..., maxit=...)(f=alFun, g=gFun, x0=x)` (alps.jl:64-66): same z, same
+    iteration count (initial state counts as 1; stop when k >= maxit or the stopping norm <= tol), and
+    the side channels alFun.fx / gFun.gz (alps.jl:68) carry f and g at the last evaluation point."""
+    n = 5000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    rng = np.random.default_rng(9)
+    mu, y, x0 = np.full(n, 0.1), rng.standard_normal(n), rng.standard_normal(n) * 0.01
+    alD = bz.AugLagFun(dev[0], dev[2], dev[3], mu.copy(), y.copy(), x0)
+    gD = bz.NonsmoothCostFun(dev[1])
+    z_d, it_d = bz.PANOCplus(tol=tol, maxit=maxit)(f=alD, g=gD, x0=x0)
+    alR = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
+    gR = ref.NonsmoothCostFun(orc[1])
+    z_r, it_r = ref.PANOCplus(tol=tol, maxit=maxit)(f=alR, g=gR, x0=x0)
+    assert it_d == it_r
+    assert rel(z_d, z_r) <= 1e-9
+    assert abs(float(alD.fx) - float(alR.fx)) <= 1e-9 * max(1.0, abs(float(alR.fx)))
+    assert abs(float(gD.gz) - float(gR.gz)) <= 1e-9 * max(1.0, abs(float(gR.gz)))
+    assert gD.gamma == pytest.approx(float(gR.gamma), rel=1e-12)
+
+
+def test_vector_bounds(bz, ref):
+    """IndBox with per-coordinate bounds as g and as D = ClosedSet(IndBox(lo, hi)) (indicatorSet.jl:8-11)."""
+    n = 20001
+    rng = np.random.default_rng(12)
+    d = bz.synth.l1_quadratic(n)
+    lo, hi = -rng.uniform(0.1, 1.0, n), rng.uniform(0.1, 1.0, n)
+    glo, ghi = -rng.uniform(0.5, 2.0, n), rng.uniform(0.5, 2.0, n)
+    dev = (bz.DiagQuadratic(d["q"], d["b"]), bz.IndBox(glo, ghi), bz.IdentityFunction(), bz.ClosedSet(bz.IndBox(lo, hi)))
+    orc = (ref.DiagQuadratic(d["q"], d["b"]), ref.IndBox(glo, ghi), ref.IdentityFunction(), ref.ClosedSet(ref.IndBox(lo, hi)))
+    x, mu, y = rng.standard_normal(n), rng.uniform(0.01, 1, n), rng.standard_normal(n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x)
+    g_ref = np.empty(n)
+    al.gradient(g_ref, x)
+    assert np.array_equal(g_dev, g_ref)
+    z_dev, _ = prob.eval_prox(x * 2, 0.5)
+    z_ref = np.empty(n)
+    orc[1].prox(z_ref, x * 2, 0.5)
+    assert np.array_equal(z_dev, z_ref)
+    prob.close()
+    a = bz.alps(*dev, np.zeros(n), np.zeros(n))
+    o = ref.alps(*orc, np.zeros(n), np.zeros(n))
+    assert a[5] == o[5] == "first_order" and a[2] == o[2] and a[3] == o[3]
+    assert rel(a[0], o[0]) <= 1e-9
+
+
+def test_float32_solver_follows_float32_oracle(bz, ref):
+    """T = Float32 end to end: same host scalar arithmetic in Float32 as the oracle; iterates agree to a
+    few float32 ulps for the first states, alps converges to the same point."""
+    n = 30000
+    d, dev, orc = make_cfg2(bz, ref, n, dtype=np.float32)
+    mu, y, x0 = np.full(n, 0.1, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 12, dtype=np.float32)
+    for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
+        assert abs(g_d - g_r) <= 1e-5 * g_r
+        assert ex <= max(2e-5, 100 * sens) and ez <= max(2e-5, 100 * sens), (k, ex, ez, sens)
+    prob.close()
+    a = bz.alps(*dev, x0, y, tol=np.float32(1e-4))
+    o = ref.alps(*orc, x0, y, tol=np.float32(1e-4))
+    assert a[0].dtype == np.float32 and a[5] == o[5] == "first_order"
+    assert np.max(np.abs(a[0] - o[0])) <= 1e-3
+
+
+def test_custom_dual_safeguard_uses_host_loop(bz, ref):
+    """alps(...; dual_safeguard=f) (alps.jl:23,62): a user callback keeps the outer loop on the host
+    and enters the device at the subsolver seam."""
+    n = 2000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    calls = []
+
+    def guard(y, cx):
+        calls.append(1)
+        np.clip(y, -5.0, 5.0, out=y)
+
+    a = bz.alps(*dev, np.zeros(n), np.zeros(n), dual_safeguard=guard)
+    o = ref.alps(*orc, np.zeros(n), np.zeros(n), dual_safeguard=guard)
+    assert len(calls) == a[2] + o[2] and a[5] == o[5]
+    assert rel(a[0], o[0]) <= 1e-8
+
+
+def test_headline_size_iterates_match_oracle(bz, ref):
+    """BASELINE config 2 at FULL size (n = 10^7): the first PANOCplus states of the exact benchmark
+    problem (persistent two-loop + fused kernel) against the numpy oracle, within 1e-10 relative."""
+    n = 10_000_000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    prob, st, rows = run_traces(bz, ref, dev, orc, n, np.full(n, 0.1), np.zeros(n), np.zeros(n), 7,
+                                minimum_gamma=float(np.finfo(float).eps))
+    for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
+        assert abs(g_d - g_r) <= 1e-13 * g_r
+        assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k}: {ex} {ez}"
+    assert sum(r[7] for r in rows) >= 5
+    p = prob.profile()
+    prob.close()

@@ -687,16 +687,23 @@ __device__ __forceinline__ double block_sum512(double v, double* sh) {
     return t;
 }
 
-// publish this block's partial, wait for all blocks, return the folded total (same bits everywhere)
-__device__ __forceinline__ double grid_phase_sum(double acc, double* row, int nb,
-                                                 unsigned long long* counter,
-                                                 unsigned long long target, int* timeout, double* sh) {
+// grid-wide phase boundary, split in two so that the loads of the next phase can be issued between
+// "arrive" and "wait": the memory system stays busy while the barrier completes.
+//   arrive: publish this block's partial (sc1 store), agent-scope release, one atomic add
+//   wait  : bounded relaxed poll, agent-scope acquire, then every block folds the nb partials (sc1
+//           loads) in the same order -> the same bits everywhere
+__device__ __forceinline__ void grid_arrive(double acc, double* row, unsigned long long* counter, double* sh) {
     const double part = block_sum512(acc, sh);
     if (threadIdx.x == 0) {
         __hip_atomic_store(row + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ double grid_wait_fold(double* row, int nb, unsigned long long* counter,
+                                                 unsigned long long target, int* timeout, double* sh) {
+    if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(4);
@@ -715,32 +722,49 @@ __device__ __forceinline__ double grid_phase_sum(double acc, double* row, int nb
 // Stream KR rounds of one or two vectors past the register-resident d with an explicit two-deep
 // software pipeline: the loads of the next group of G rounds are issued before the current group
 // is consumed, and sched_barriers keep the compiler from sinking them back to their uses (with d
-// holding 160 of the 256 VGPRs its scheduler otherwise keeps only 2 loads in flight).
-template <class T, int KR, int G, bool TWO, class F>
-__device__ __forceinline__ void persist_stream(const T* __restrict__ p0, const T* __restrict__ p1,
-                                               int64_t first, int stride_e, F&& f) {
-    static_assert(KR % G == 0, "KR must be a multiple of the pipeline group");
-    Pack<T> bv[2][G], bw[2][G];
+// holding 160 of the 256 VGPRs its scheduler otherwise keeps only 2 loads in flight).  The first
+// group is loaded by persist_prefetch, which the kernel calls BEFORE waiting on the phase barrier.
+template <class T, int G, bool TWO>
+__device__ __forceinline__ void persist_prefetch(const T* __restrict__ p0, const T* __restrict__ p1,
+                                                 int64_t first, int stride_e, Pack<T> (&pv)[G],
+                                                 Pack<T> (&pw)[G]) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int64_t i0 = first + (int64_t)g * stride_e;
-        bv[0][g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
-        if (TWO) bw[0][g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+        pv[g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
+        if (TWO) pw[g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <class T, int KR, int G, bool TWO, class F>
+__device__ __forceinline__ void persist_stream(const T* __restrict__ p0, const T* __restrict__ p1,
+                                               int64_t first, int stride_e, Pack<T> (&pv)[G],
+                                               Pack<T> (&pw)[G], F&& f) {
+    static_assert(KR % G == 0, "KR must be a multiple of the pipeline group");
+    Pack<T> qv[G], qw[G];
 #pragma unroll
     for (int kb = 0; kb < KR; kb += G) {
-        const int cur = (kb / G) & 1, nxt = cur ^ 1;
+        const bool even = ((kb / G) & 1) == 0;
         if (kb + G < KR) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int64_t i0 = first + (int64_t)(kb + G + g) * stride_e;
-                bv[nxt][g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
-                if (TWO) bw[nxt][g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+                if (even) {
+                    qv[g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
+                    if (TWO) qw[g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+                } else {
+                    pv[g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
+                    if (TWO) pw[g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < G; ++g) f(kb + g, bv[cur][g], TWO ? bw[cur][g] : bv[cur][g]);
+        for (int g = 0; g < G; ++g) {
+            if (even) f(kb + g, pv[g], TWO ? pw[g] : pv[g]);
+            else f(kb + g, qv[g], TWO ? qw[g] : qv[g]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -768,10 +792,12 @@ k_twoloop_persist(PersistArgs<T> a) {
     // LDS pointer so the KR pack offsets are not hoisted out of the phase loops (2 VGPRs each).
 #define BZ_P_STRIDE (*(volatile int*)&stride_sh)
     constexpr int G = 4;
+    Pack<T> pv[G], pw[G];      // first group of the coming phase, loaded across the phase barrier
 
     // phase 0: d = -res ; <s_0, d>
     double acc = 0.0;
-    persist_stream<T, KR, G, true>(a.res, a.S[0], first, BZ_P_STRIDE,
+    persist_prefetch<T, G, true>(a.res, a.S[0], first, BZ_P_STRIDE, pv, pw);
+    persist_stream<T, KR, G, true>(a.res, a.S[0], first, BZ_P_STRIDE, pv, pw,
         [&](int k, const Pack<T>& r, const Pack<T>& s) {
 #pragma unroll
             for (int e = 0; e < N; ++e) {
@@ -782,14 +808,16 @@ k_twoloop_persist(PersistArgs<T> a) {
         });
     // loop 1: d -= alpha_j y_j ; <s_{j+1}, d>          (j = 0 .. m-2)
     for (int j = 0; j + 1 < m; ++j) {
+        double* row = a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE;
         target += nb;
-        const double tot = grid_phase_sum(acc, a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE, nb, a.counter,
-                                          target, a.timeout, sh);
+        grid_arrive(acc, row, a.counter, sh);
+        persist_prefetch<T, G, true>(a.Y[j], a.S[j + 1], first, BZ_P_STRIDE, pv, pw);
+        const double tot = grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
         const T coef = -al;
         acc = 0.0;
-        persist_stream<T, KR, G, true>(a.Y[j], a.S[j + 1], first, BZ_P_STRIDE,
+        persist_stream<T, KR, G, true>(a.Y[j], a.S[j + 1], first, BZ_P_STRIDE, pv, pw,
             [&](int k, const Pack<T>& v, const Pack<T>& w) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
@@ -803,15 +831,17 @@ k_twoloop_persist(PersistArgs<T> a) {
     // middle: d = H (d - alpha_{m-1} y_{m-1}) ; <y_{m-1}, d>
     {
         const int j = m - 1;
+        double* row = a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE;
         target += nb;
-        const double tot = grid_phase_sum(acc, a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE, nb, a.counter,
-                                          target, a.timeout, sh);
+        grid_arrive(acc, row, a.counter, sh);
+        persist_prefetch<T, G, false>(a.Y[j], a.Y[j], first, BZ_P_STRIDE, pv, pw);
+        const double tot = grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
         const T coef = -al;
         const T Hs = a.H;
         acc = 0.0;
-        persist_stream<T, KR, G, false>(a.Y[j], a.Y[j], first, BZ_P_STRIDE,
+        persist_stream<T, KR, G, false>(a.Y[j], a.Y[j], first, BZ_P_STRIDE, pv, pw,
             [&](int k, const Pack<T>& v, const Pack<T>&) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
@@ -826,13 +856,15 @@ k_twoloop_persist(PersistArgs<T> a) {
     __syncthreads();    // alpha_sh complete
     // loop 2: d += (alpha_j - beta_j) s_j ; <y_{j-1}, d>   (j = m-1 .. 1)
     for (int j = m - 1; j >= 1; --j) {
+        double* row = a.parts + (size_t)(a.slot_loop2 + j) * PSTRIDE;
         target += nb;
-        const double tot = grid_phase_sum(acc, a.parts + (size_t)(a.slot_loop2 + j) * PSTRIDE, nb, a.counter,
-                                          target, a.timeout, sh);
+        grid_arrive(acc, row, a.counter, sh);
+        persist_prefetch<T, G, true>(a.S[j], a.Y[j - 1], first, BZ_P_STRIDE, pv, pw);
+        const double tot = grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
         const T beta = T(tot) / a.ys[j];
         const T coef = alpha_sh[j] - beta;
         acc = 0.0;
-        persist_stream<T, KR, G, true>(a.S[j], a.Y[j - 1], first, BZ_P_STRIDE,
+        persist_stream<T, KR, G, true>(a.S[j], a.Y[j - 1], first, BZ_P_STRIDE, pv, pw,
             [&](int k, const Pack<T>& v, const Pack<T>& w) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {

@@ -689,28 +689,51 @@ __device__ __forceinline__ double block_sum512(double v, double* sh) {
 
 // grid-wide phase boundary, split in two so that the loads of the next phase can be issued between
 // "arrive" and "wait": the memory system stays busy while the barrier completes.
-//   arrive: publish this block's partial (sc1 store), agent-scope release, one atomic add
-//   wait  : bounded relaxed poll, agent-scope acquire, then every block folds the nb partials (sc1
-//           loads) in the same order -> the same bits everywhere
+// Every byte handed between workgroups is an 8-byte agent-scope atomic on BOTH sides (sc1 store /
+// sc1 load: written through to memory, never served from a non-coherent L1/L2 copy), the storing
+// lane drains its store (s_waitcnt vmcnt(0)) before it signals, and exactly one lane per workgroup
+// signals: the hand-off form measured valid on gfx950 without release/acquire fences
+// (MI355X_MICROARCH.md, "Valid forms" table row 1), which saves ~1.7 us + ~1.7 us per barrier.
+// The arrival counter is sharded 8 ways (blockIdx % 8 = the XCD under round-robin dispatch; a
+// speed assumption only) so at most nb/8 adds contend per word; 8 lanes poll the 8 shards.
+//   arrive: publish this block's partial, drain, one atomic add on this block's shard
+//   wait  : bounded poll until the shards sum to `target`, then every block folds the nb partials
+//           in the same order -> the same bits everywhere
+constexpr int PSHARDS = 8;
+constexpr int PSHARD_STRIDE = 16;      // unsigned long long words: 128 B between shards
+
 __device__ __forceinline__ void grid_arrive(double acc, double* row, unsigned long long* counter, double* sh) {
     const double part = block_sum512(acc, sh);
     if (threadIdx.x == 0) {
         __hip_atomic_store(row + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(counter + (blockIdx.x % PSHARDS) * PSHARD_STRIDE, 1ull, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __device__ __forceinline__ double grid_wait_fold(double* row, int nb, unsigned long long* counter,
                                                  unsigned long long target, int* timeout, double* sh) {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {            // wave 0 polls: lanes 0..7 read one shard each
         unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > PSPIN_LIMIT) { *timeout = 1; break; }
+        for (;;) {
+            unsigned long long c = 0;
+            if (threadIdx.x < PSHARDS)
+                c = __hip_atomic_load(counter + threadIdx.x * PSHARD_STRIDE, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+            // sum of the 8 shards (lanes >= 8 contribute 0), broadcast from lane 0
+            unsigned lo = (unsigned)c, hi = (unsigned)(c >> 32);
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {
+                unsigned long long t = ((unsigned long long)__shfl_down(hi, o, 64) << 32) | __shfl_down(lo, o, 64);
+                c += t;
+                lo = (unsigned)c; hi = (unsigned)(c >> 32);
+            }
+            const unsigned long long tot = ((unsigned long long)__shfl(hi, 0, 64) << 32) | __shfl(lo, 0, 64);
+            if (tot >= target) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > PSPIN_LIMIT) { if (threadIdx.x == 0) *timeout = 1; break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: keep the loads below the poll
     }
     __syncthreads();
     double v = 0.0;

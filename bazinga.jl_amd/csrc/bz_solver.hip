@@ -173,8 +173,7 @@ template <class T> class Solver final : public SolverBase {
         BZ_HIP(hipHostMalloc((void**)&ptimeout_, sizeof(int), hipHostMallocMapped));
         *ptimeout_ = 0;
         BZ_HIP(hipHostGetDevicePointer((void**)&ptimeout_dev_, ptimeout_, 0));
-        pcounter_.alloc(2);
-        BZ_HIP(hipMemsetAsync(pcounter_.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        pcounter_.alloc(PSHARDS * PSHARD_STRIDE);      // zero-filled by alloc
         for (int s = 0; s < SL_COUNT; ++s) { grp_first[s] = s; grp_cnt[s] = 1; slot_n[s] = grid; }
         slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
         BZ_HIP(hipStreamSynchronize(ctx->stream));

@@ -15,7 +15,7 @@ BZ_OK = 0
 BZ_ERR_ARG, BZ_ERR_HIP, BZ_ERR_UNSUPPORTED, BZ_ERR_STATE, BZ_ERR_COMM, BZ_ERR_MU = -1, -2, -3, -4, -5, -6
 BZ_F64, BZ_F32 = 0, 1
 BZ_F_ZERO, BZ_F_DIAG_QUADRATIC, BZ_F_STENCIL5, BZ_F_LEAST_SQUARES, BZ_F_QUADRATIC = 0, 1, 2, 3, 4
-BZ_G_ZERO, BZ_G_NORM_L1, BZ_G_NORM_L1_NONNEG, BZ_G_NORM_L1_BOX, BZ_G_IND_BOX = 0, 1, 2, 3, 4
+BZ_G_ZERO, BZ_G_NORM_L1, BZ_G_NORM_L1_NONNEG, BZ_G_NORM_L1_BOX, BZ_G_IND_BOX, BZ_G_NORM_L0_BOX = 0, 1, 2, 3, 4, 5
 BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
 NUM_KERNEL_CATEGORIES = 12

@@ -11,6 +11,7 @@ struct bz_problem {
     bz_ctx* ctx;
     bz::SolverBase* s;
     int dtype;
+    int device;       // kept here so destroy never dereferences a context that was freed first
 };
 
 namespace {
@@ -99,7 +100,7 @@ int bz_problem_create(bz_ctx* ctx, const bz_problem_desc* d, bz_problem** out) {
     return guard([&] {
         need(ctx, "ctx"); need(d, "desc"); need(out, "out");
         BZ_HIP(hipSetDevice(ctx->c.device));
-        auto* p = new bz_problem{ctx, nullptr, d->dtype};
+        auto* p = new bz_problem{ctx, nullptr, d->dtype, ctx->c.device};
         try {
             p->s = bz::make_solver(&ctx->c, *d);
         } catch (...) {
@@ -112,7 +113,7 @@ int bz_problem_create(bz_ctx* ctx, const bz_problem_desc* d, bz_problem** out) {
 
 void bz_problem_destroy(bz_problem* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->c.device);
+    (void)hipSetDevice(p->device);
     delete p->s;
     delete p;
 }

@@ -203,10 +203,25 @@ __device__ __forceinline__ ALOut<T> al_elem(int f_kind, int D_kind, T x, T q, T 
 }
 
 // prox!(z, g, y, gamma) element; gl = gamma*lambda.  Returns z, adds to gsum.
+__device__ __forceinline__ double sqrt_rn(double v) { return __dsqrt_rn(v); }
+__device__ __forceinline__ float sqrt_rn(float v) { return __fsqrt_rn(v); }
+
 template <class T>
 __device__ __forceinline__ T prox_elem(int g_kind, T y, T gl, T u, T lo, T hi, T& gterm) {
     T z;
     switch (g_kind) {
+    case BZ_G_NORM_L0_BOX: {        // normL0Box.jl:33-58 ; gterm counts the nonzeros
+        z = T(0); gterm = T(0);
+        if (u != T(0) && y > sqrt_rn(gl)) {
+            if (y > u) {
+                const T d = u - y;
+                if (y * y > gl + d * d) { z = y; gterm = T(1); }
+            } else {
+                z = y; gterm = T(1);
+            }
+        }
+        break;
+    }
     case BZ_G_NORM_L1: {            // ProximalOperators.NormL1
         z = y + (y <= -gl ? gl : (y >= gl ? -gl : -y));
         gterm = z > T(0) ? z : -z;
@@ -250,7 +265,7 @@ __device__ __forceinline__ void load_params(const ElemParams<T>& P, int64_t i0, 
         L.dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
     }
     if (need_g) {
-        L.gu = (P.g_kind == BZ_G_NORM_L1_BOX) ? ld(P.g_u, i0, cnt) : splat(T(0));
+        L.gu = (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX) ? ld(P.g_u, i0, cnt) : splat(T(0));
         L.glo = P.g_lo_vec ? ld(P.g_lo_vec, i0, cnt) : splat(P.g_lo);
         L.ghi = P.g_hi_vec ? ld(P.g_hi_vec, i0, cnt) : splat(P.g_hi);
     }

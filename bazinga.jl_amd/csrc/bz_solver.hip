@@ -79,11 +79,11 @@ template <class T> class Solver final : public SolverBase {
             if (ctx->nranks > 1)
                 throw Error(BZ_ERR_UNSUPPORTED, "Stencil5pt is not sharded (needs a halo exchange)");
         }
-        if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_IND_BOX)
+        if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_NORM_L0_BOX)
             throw Error(BZ_ERR_ARG, "unknown g kind");
         if (d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_BOX) throw Error(BZ_ERR_ARG, "unknown D kind");
         if ((d.g_kind == BZ_G_NORM_L1 || d.g_kind == BZ_G_NORM_L1_NONNEG ||
-             d.g_kind == BZ_G_NORM_L1_BOX) && d.g_lambda < 0)
+             d.g_kind == BZ_G_NORM_L1_BOX || d.g_kind == BZ_G_NORM_L0_BOX) && d.g_lambda < 0)
             throw Error(BZ_ERR_ARG, "parameter lambda must be nonnegative");
         BZ_HIP(hipSetDevice(ctx->device));
         const int64_t nchunks = (n + PackN<T>::N - 1) / PackN<T>::N;
@@ -143,8 +143,8 @@ template <class T> class Solver final : public SolverBase {
             P.b = b_.p;
         }
         P.g_lambda = (T)d.g_lambda;
-        if (d.g_kind == BZ_G_NORM_L1_BOX) {
-            if (!d.g_u) throw Error(BZ_ERR_ARG, "NormL1Box needs u");
+        if (d.g_kind == BZ_G_NORM_L1_BOX || d.g_kind == BZ_G_NORM_L0_BOX) {
+            if (!d.g_u) throw Error(BZ_ERR_ARG, "NormL1Box / NormL0Box need u");
             upload(gu_, d.g_u, n); P.g_u = gu_.p;
         }
         P.g_lo = (T)d.g_lo; P.g_hi = (T)d.g_hi;
@@ -545,7 +545,7 @@ template <class T> class Solver final : public SolverBase {
     T f_value(double fsum) const { return fscale == T(1) ? T(fsum) : fscale * T(fsum); }
     T g_value(double gsum) const {
         switch (desc.g_kind) {
-        case BZ_G_NORM_L1: case BZ_G_NORM_L1_NONNEG: case BZ_G_NORM_L1_BOX:
+        case BZ_G_NORM_L1: case BZ_G_NORM_L1_NONNEG: case BZ_G_NORM_L1_BOX: case BZ_G_NORM_L0_BOX:
             return P.g_lambda * T(gsum);
         default: return T(0);
         }
@@ -781,7 +781,7 @@ template <class T> class Solver final : public SolverBase {
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
             // block per CU) and the vector must be long enough for 2m-1 grid barriers to beat 2m launches
-            int64_t min_n = 2000000;
+            int64_t min_n = 300000;      // below this 2m short launches beat 2m-1 grid barriers (~5 us each)
             if (const char* e = getenv("BZ_PERSIST_MIN_N")) min_n = atoll(e);
             persist_ok = o.persist && !ctx->comm && persist_kr > 0 && n >= min_n;
         }

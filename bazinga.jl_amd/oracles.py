@@ -114,6 +114,18 @@ class NormL1Box(ProximableFunction):
         self.lam = float(lam)
 
 
+class NormL0Box(ProximableFunction):
+    """src/proxoperators/normL0Box.jl:12-58: lambda*nnz(x) + indicator of [0, u]."""
+
+    def __init__(self, lam=1.0, *, u):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")
+        self.u = np.ascontiguousarray(u)
+        if np.any(self.u < 0):
+            raise ValueError("vector u must have nonnegative entries")
+        self.lam = float(lam)
+
+
 class IndBox(ProximableFunction):
     """ProximalOperators.IndBox(lb, ub) (test_nonconvex_qp.jl:15); scalar or vector bounds."""
 
@@ -222,6 +234,9 @@ def lower(f, g, c, D, n, ny, dtype):
         d.g_kind, d.g_lambda = L.BZ_G_NORM_L1_NONNEG, g.lam
     elif isinstance(g, NormL1Box):
         d.g_kind, d.g_lambda = L.BZ_G_NORM_L1_BOX, g.lam
+        d.g_u = ptr(_vec(g.u, dtype, n, "u"))
+    elif isinstance(g, NormL0Box):
+        d.g_kind, d.g_lambda = L.BZ_G_NORM_L0_BOX, g.lam
         d.g_u = ptr(_vec(g.u, dtype, n, "u"))
     elif isinstance(g, IndBox):
         d.g_kind = L.BZ_G_IND_BOX

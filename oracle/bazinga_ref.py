@@ -236,6 +236,32 @@ class NormL1Box:
         return T(self.lam) * _sum(y)
 
 
+class NormL0Box:
+    """src/proxoperators/normL0Box.jl:12-58"""
+
+    def __init__(self, lam=1.0, *, u):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")
+        if np.any(np.asarray(u) < 0):
+            raise ValueError("vector u must have nonnegative entries")
+        self.lam = lam
+        self.u = np.asarray(u)
+
+    def __call__(self, x):
+        return self.lam * x.dtype.type(np.count_nonzero(x))
+
+    def prox(self, y, x, gamma):
+        T = x.dtype.type
+        gl2 = T(gamma) * T(self.lam)
+        u = self.u.astype(x.dtype, copy=False)
+        big = x > np.sqrt(gl2)
+        above = x > u
+        keep_above = x * x > gl2 + (u - x) ** 2
+        nz = (u != 0) & big & (~above | keep_above)
+        y[...] = np.where(nz, x, T(0))
+        return T(self.lam) * _sum(nz.astype(x.dtype))
+
+
 class IndBox:
     """ProximalOperators.IndBox(lb, ub) (test_nonconvex_qp.jl:15): prox = clamp,
     value 0.  lb/ub scalar or array."""

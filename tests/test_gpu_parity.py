@@ -24,6 +24,9 @@ def make_cfg2(bz, ref, n, seed_start=0, D="box", dtype=np.float64, g="l1"):
     elif g == "l1box":
         u = np.full(n, 0.75, dtype)
         g_d, g_r = bz.NormL1Box(d["lam"], u=u), ref.NormL1Box(d["lam"], u=u)
+    elif g == "l0box":
+        u = np.where(np.arange(n) % 7 == 0, 0.0, 0.6).astype(dtype)
+        g_d, g_r = bz.NormL0Box(0.3, u=u), ref.NormL0Box(0.3, u=u)
     elif g == "indbox":
         g_d, g_r = bz.IndBox(-0.5, 0.5), ref.IndBox(dtype(-0.5), dtype(0.5))
     else:
@@ -62,7 +65,7 @@ def test_al_gradient_bit_exact(bz, ref, n, D):
     prob.close()
 
 
-@pytest.mark.parametrize("g", ["l1", "nonneg", "l1box", "indbox", "zero"])
+@pytest.mark.parametrize("g", ["l1", "nonneg", "l1box", "l0box", "indbox", "zero"])
 @pytest.mark.parametrize("n", [3, 1001, 70001])
 def test_prox_bit_exact(bz, ref, n, g):
     """K3 prox!(z, g, x, gamma): soft-threshold family, element-wise bit-exact."""
@@ -182,7 +185,7 @@ def test_panoc_iterates_match_oracle(bz, ref, n, D):
         prob.close()
 
 
-@pytest.mark.parametrize("g", ["l1", "nonneg", "l1box", "indbox", "zero"])
+@pytest.mark.parametrize("g", ["l1", "nonneg", "l1box", "l0box", "indbox", "zero"])
 def test_fused_equals_generic_bitwise(bz, ref, g):
     """The single-pass fused kernel and the generic kernel chain are the same arithmetic:
     iterates and scalars must be identical to the last bit."""

@@ -7,7 +7,7 @@ from . import _lib, synth
 from ._lib import BazingaHipError
 from .device import Context, Problem, default_context, set_default_context, shard_bounds
 from .oracles import (ClosedSet, DenseAffine, DiagQuadratic, FreeSet, IdentityFunction, IndBox, IndFree, IndicatorSet,
-                      LeastSquares, NormL0Box, Quadratic,
+                      LeastSquares, NormL0Box, NormLpPowerBox, NormLpPowerNonneg, Quadratic,
                       NormL1, NormL1Box, NormL1Nonneg, Stencil5ptQuadratic, UnsupportedOracle, Zero, ZeroSet)
 from .solvers import (LBFGS, AugLagFun, AugLagUpdate, NonsmoothCostFun, PANOCplus, alps,
                       default_dual_safeguard, default_penalty_parameter, default_subsolver)

@@ -16,6 +16,7 @@ BZ_ERR_ARG, BZ_ERR_HIP, BZ_ERR_UNSUPPORTED, BZ_ERR_STATE, BZ_ERR_COMM, BZ_ERR_MU
 BZ_F64, BZ_F32 = 0, 1
 BZ_F_ZERO, BZ_F_DIAG_QUADRATIC, BZ_F_STENCIL5, BZ_F_LEAST_SQUARES, BZ_F_QUADRATIC = 0, 1, 2, 3, 4
 BZ_G_ZERO, BZ_G_NORM_L1, BZ_G_NORM_L1_NONNEG, BZ_G_NORM_L1_BOX, BZ_G_IND_BOX, BZ_G_NORM_L0_BOX = 0, 1, 2, 3, 4, 5
+BZ_G_NORM_LP_NONNEG, BZ_G_NORM_LP_BOX = 6, 7
 BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
 NUM_KERNEL_CATEGORIES = 12
@@ -35,7 +36,7 @@ class ProblemDesc(C.Structure):
         ("n", C.c_int64), ("ny", C.c_int64),
         ("f_q", C.c_void_p), ("f_b", C.c_void_p), ("f_grid_nx", C.c_int64), ("f_grid_ny", C.c_int64),
         ("f_A", C.c_void_p), ("f_rows", C.c_int64),
-        ("g_lambda", C.c_double), ("g_u", C.c_void_p), ("g_lo", C.c_double), ("g_hi", C.c_double),
+        ("g_lambda", C.c_double), ("g_p", C.c_double), ("g_u", C.c_void_p), ("g_lo", C.c_double), ("g_hi", C.c_double),
         ("g_lo_vec", C.c_void_p), ("g_hi_vec", C.c_void_p),
         ("c_A", C.c_void_p), ("c_b", C.c_void_p),
         ("D_lo", C.c_double), ("D_hi", C.c_double), ("D_lo_vec", C.c_void_p), ("D_hi_vec", C.c_void_p),

@@ -52,6 +52,7 @@ template <class T> struct ElemParams {
     const T* mu;
     const T* muy;
     T g_lambda;
+    T g_p;                 // NormLpPower*: exponent p in (0,1); g_lambda holds alpha
     const T* g_u;
     T g_lo, g_hi;
     const T* g_lo_vec;
@@ -206,9 +207,44 @@ __device__ __forceinline__ ALOut<T> al_elem(int f_kind, int D_kind, T x, T q, T 
 __device__ __forceinline__ double sqrt_rn(double v) { return __dsqrt_rn(v); }
 __device__ __forceinline__ float sqrt_rn(float v) { return __fsqrt_rn(v); }
 
+// scalar Newton solve of  min_z  alpha z^p + 0.5 (z - x)^2  over z >= 0 [and z <= u]
+// (src/proxoperators/normLpNonneg.jl:44-84, normLpBox.jl:47-97); alpha = a*gamma.  zp returns z^p.
 template <class T>
-__device__ __forceinline__ T prox_elem(int g_kind, T y, T gl, T u, T lo, T hi, T& gterm) {
+__device__ __noinline__ T lp_prox(T x, T p, T alpha, T u, bool box, T& zp) {
+    zp = T(0);
+    if (x <= T(0) || (box && u == T(0))) return T(0);
+    const T ap = alpha * p;
+    const T zbar = pow(T(1) / (ap * (T(1) - p)), T(1) / (p - T(2)));
+    const T psi = zbar + ap * pow(zbar, p - T(1));
+    if (psi >= x) return T(0);
+    T z = zbar + (box ? T(0.1) : T(1));          // perturbation to the right
+    for (int iter = 0; iter < 1000; ++iter) {
+        const T dphi = z - x + ap * pow(z, p - T(1));
+        if ((dphi < T(0) ? -dphi : dphi) <= T(1e-12)) break;
+        const T ddphi = T(1) + ap * (p - T(1)) * pow(z, p - T(2));
+        z -= dphi / ddphi;
+    }
+    const T phi0 = T(0.5) * (x * x);
+    const T dz = z - x;
+    const T pz = pow(z, p);
+    if (phi0 <= T(0.5) * (dz * dz) + alpha * pz) return T(0);
+    if (box && z > u) {
+        const T du = u - x;
+        const T pu = pow(u, p);
+        if (T(0.5) * (du * du) + alpha * pu < phi0) { zp = pu; return u; }
+        return T(0);
+    }
+    zp = pz;
+    return z;
+}
+
+template <class T, bool LP = false>
+__device__ __forceinline__ T prox_elem(int g_kind, T y, T gl, T u, T lo, T hi, T& gterm, T gp = T(0)) {
     T z;
+    if (LP) {                       // the Newton/pow kinds live in their own kernel instantiation
+        if (g_kind == BZ_G_NORM_LP_NONNEG) return lp_prox(y, gp, gl, T(0), false, gterm);
+        if (g_kind == BZ_G_NORM_LP_BOX) return lp_prox(y, gp, gl, u, true, gterm);
+    }
     switch (g_kind) {
     case BZ_G_NORM_L0_BOX: {        // normL0Box.jl:33-58 ; gterm counts the nonzeros
         z = T(0); gterm = T(0);
@@ -265,7 +301,8 @@ __device__ __forceinline__ void load_params(const ElemParams<T>& P, int64_t i0, 
         L.dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
     }
     if (need_g) {
-        L.gu = (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX) ? ld(P.g_u, i0, cnt) : splat(T(0));
+        L.gu = (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX || P.g_kind == BZ_G_NORM_LP_BOX)
+                   ? ld(P.g_u, i0, cnt) : splat(T(0));
         L.glo = P.g_lo_vec ? ld(P.g_lo_vec, i0, cnt) : splat(P.g_lo);
         L.ghi = P.g_hi_vec ? ld(P.g_hi_vec, i0, cnt) : splat(P.g_hi);
     }
@@ -933,7 +970,7 @@ k_twoloop_persist(PersistArgs<T> a) {
 //   slots: +0 sum g terms (multiply by lambda on the host), +1 <g,res>, +2 ||res||^2
 //   g == nullptr: pure prox of x (used for prox_{eps g}(x0), alps.jl:38)
 // ---------------------------------------------------------------------------
-template <class T>
+template <class T, bool LP = false>
 __global__ void __launch_bounds__(BLOCK)
 k_fbstep(const T* __restrict__ x, const T* __restrict__ g, T gamma, ElemParams<T> P,
          T* __restrict__ z, T* __restrict__ res, int64_t n, double* __restrict__ parts,
@@ -952,7 +989,7 @@ k_fbstep(const T* __restrict__ x, const T* __restrict__ g, T gamma, ElemParams<T
             T y = px.v[e];
             if (g) { T t = gamma * pg.v[e]; y = px.v[e] - t; }
             T gterm;
-            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            T zz = prox_elem<T, LP>(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm, P.g_p);
             T r = px.v[e] - zz;
             pz.v[e] = zz; pr.v[e] = r;
             if (e < cnt) {

@@ -79,7 +79,7 @@ template <class T> class Solver final : public SolverBase {
             if (ctx->nranks > 1)
                 throw Error(BZ_ERR_UNSUPPORTED, "Stencil5pt is not sharded (needs a halo exchange)");
         }
-        if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_NORM_L0_BOX)
+        if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_NORM_LP_BOX)
             throw Error(BZ_ERR_ARG, "unknown g kind");
         if (d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_BOX) throw Error(BZ_ERR_ARG, "unknown D kind");
         if ((d.g_kind == BZ_G_NORM_L1 || d.g_kind == BZ_G_NORM_L1_NONNEG ||
@@ -143,8 +143,15 @@ template <class T> class Solver final : public SolverBase {
             P.b = b_.p;
         }
         P.g_lambda = (T)d.g_lambda;
-        if (d.g_kind == BZ_G_NORM_L1_BOX || d.g_kind == BZ_G_NORM_L0_BOX) {
-            if (!d.g_u) throw Error(BZ_ERR_ARG, "NormL1Box / NormL0Box need u");
+        P.g_p = (T)d.g_p;
+        lp_g = d.g_kind == BZ_G_NORM_LP_NONNEG || d.g_kind == BZ_G_NORM_LP_BOX;
+        if (lp_g) {
+            if (!(d.g_p > 0)) throw Error(BZ_ERR_ARG, "p must be positive");
+            if (!(d.g_p < 1)) throw Error(BZ_ERR_ARG, "p must be smaller than one");
+            if (d.g_lambda < 0) throw Error(BZ_ERR_ARG, "alpha must be nonnegative");
+        }
+        if (d.g_kind == BZ_G_NORM_L1_BOX || d.g_kind == BZ_G_NORM_L0_BOX || d.g_kind == BZ_G_NORM_LP_BOX) {
+            if (!d.g_u) throw Error(BZ_ERR_ARG, "NormL1Box / NormL0Box / NormLpPowerBox need u");
             upload(gu_, d.g_u, n); P.g_u = gu_.p;
         }
         P.g_lo = (T)d.g_lo; P.g_hi = (T)d.g_hi;
@@ -253,8 +260,7 @@ template <class T> class Solver final : public SolverBase {
 
     void eval_prox(const void* x, double gam, void* z, double* gz) override {
         copy_in(TMP_.p, x, n);
-        launch(C_FB, k_fbstep<T>, grid, TMP_.p, (const T*)nullptr, (T)gam, P, D_.p, (T*)nullptr, n,
-               parts_.p, (int)SL_GSUM);
+        fbstep(TMP_.p, nullptr, (T)gam, D_.p, nullptr, SL_GSUM);
         gather(SL_GSUM, 3, 0u);
         auto v = collect({SL_GSUM}, 0u);
         *gz = (double)g_value(v[0]);
@@ -310,8 +316,7 @@ template <class T> class Solver final : public SolverBase {
         T* x = X_[0].p;
         copy_in(TMP_.p, x0, n);
         // prox!(x, gFun, x0, eps(T))                                   alps.jl:38
-        launch(C_FB, k_fbstep<T>, grid, (const T*)TMP_.p, (const T*)nullptr, epsT, P, x, (T*)nullptr, n,
-               parts_.p, (int)SL_GSUM);
+        fbstep(TMP_.p, nullptr, epsT, x, nullptr, SL_GSUM);
         gather(SL_GSUM, 3, 0u);
         // objx = f(x) + gFun.gz                                        alps.jl:39
         fvalue(x, SL_AUX);
@@ -399,7 +404,7 @@ template <class T> class Solver final : public SolverBase {
     DBuf<T> A_, cb_, CX_, YU_, GT_;          // DenseAffine c: A[ny][n], b, c(x), yupd, A'v row-chunk partials
     int rows_per_chunk = 1, nrowchunks = 1;
     DBuf<T> FA_, fb_, FR_, DFX_;             // dense f: matrix, vector, residual / Qx, gradient of f
-    bool dense_f = false;
+    bool dense_f = false, lp_g = false;
     int64_t frows = 0, npad = 0;
     int f_rows_per_chunk = 1, f_nrowchunks = 1;
     T fscale = T(1);                         // f(x) = fscale * (sum of the f partials)
@@ -536,6 +541,12 @@ template <class T> class Solver final : public SolverBase {
         return std::vector<double>(host_out_, host_out_ + a.n);
     }
 
+    // forward-backward step kernel; the Newton/pow prox kinds use their own instantiation so the
+    // common kinds keep their register budget
+    void fbstep(const T* x, const T* g, T gam, T* z, T* res, int slot0) {
+        if (lp_g) launch(C_FB, k_fbstep<T, true>, grid, x, g, gam, P, z, res, n, parts_.p, slot0);
+        else launch(C_FB, k_fbstep<T, false>, grid, x, g, gam, P, z, res, n, parts_.p, slot0);
+    }
     T al_value(double fsum, double pensum) const {   // auglagfun.jl:78,81-82
         T lx = T(0.5) * T(pensum);
         lx += f_value(fsum);
@@ -546,6 +557,7 @@ template <class T> class Solver final : public SolverBase {
     T g_value(double gsum) const {
         switch (desc.g_kind) {
         case BZ_G_NORM_L1: case BZ_G_NORM_L1_NONNEG: case BZ_G_NORM_L1_BOX: case BZ_G_NORM_L0_BOX:
+        case BZ_G_NORM_LP_NONNEG: case BZ_G_NORM_LP_BOX:
             return P.g_lambda * T(gsum);
         default: return T(0);
         }
@@ -776,7 +788,7 @@ template <class T> class Solver final : public SolverBase {
         alloc_history();
         lbfgs_reset_all();
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
-        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY &&
+        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
@@ -811,8 +823,7 @@ template <class T> class Solver final : public SolverBase {
         // y = x - gamma grad ; z, g_z = prox(g, y, gamma) ; res = x - z ; backtrack_stepsize!
         T f_z = T(0);
         for (;;) {
-            launch(C_FB, k_fbstep<T>, grid, (const T*)x, (const T*)GX_.p, gamma, P, Z_[zc].p, RES_[rc].p, n,
-                   parts_.p, (int)SL_GSUM);
+            fbstep(x, GX_.p, gamma, Z_[zc].p, RES_[rc].p, SL_GSUM);
             gather(SL_GSUM, 3, 0u);
             ++n_prox;
             algrad(Z_[zc].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
@@ -896,8 +907,7 @@ template <class T> class Solver final : public SolverBase {
         for (int k = 1; k <= max_bt; ++k) {
             if (!have_trial) {
                 if (!gx_valid) { algrad(X_[xcur].p, GX_.p, SL_FXD); gx_valid = true; }
-                launch(C_FB, k_fbstep<T>, grid, (const T*)X_[xcur].p, (const T*)GX_.p, gamma, P, Z_[zn].p,
-                       RES_[rn].p, n, parts_.p, (int)SL_GSUM);
+                fbstep(X_[xcur].p, GX_.p, gamma, Z_[zn].p, RES_[rn].p, SL_GSUM);
                 gather(SL_GSUM, 3, 0u);
                 ++n_prox;
                 algrad(Z_[zn].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;

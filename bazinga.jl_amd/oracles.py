@@ -126,6 +126,35 @@ class NormL0Box(ProximableFunction):
         self.lam = float(lam)
 
 
+class NormLpPowerNonneg(ProximableFunction):
+    """src/proxoperators/normLpNonneg.jl:14-40: alpha * sum x^p on x >= 0, 0 < p < 1."""
+
+    def __init__(self, p, *, alpha=1.0):
+        if p <= 0:
+            raise ValueError("p must be positive")
+        if p >= 1:
+            raise ValueError("p must be smaller than one")
+        if alpha < 0:
+            raise ValueError("alpha must be nonnegative")
+        self.p, self.alpha = float(p), float(alpha)
+
+
+class NormLpPowerBox(ProximableFunction):
+    """src/proxoperators/normLpBox.jl:11-45: alpha * sum x^p on 0 <= x <= u, 0 < p < 1."""
+
+    def __init__(self, p, alpha=1.0, *, u):
+        if p <= 0:
+            raise ValueError("p must be positive")
+        if p >= 1:
+            raise ValueError("p must be smaller than one")
+        if alpha < 0:
+            raise ValueError("alpha must be nonnegative")
+        self.u = np.ascontiguousarray(u)
+        if np.any(self.u < 0):
+            raise ValueError("vector u must have nonnegative entries")
+        self.p, self.alpha = float(p), float(alpha)
+
+
 class IndBox(ProximableFunction):
     """ProximalOperators.IndBox(lb, ub) (test_nonconvex_qp.jl:15); scalar or vector bounds."""
 
@@ -237,6 +266,11 @@ def lower(f, g, c, D, n, ny, dtype):
         d.g_u = ptr(_vec(g.u, dtype, n, "u"))
     elif isinstance(g, NormL0Box):
         d.g_kind, d.g_lambda = L.BZ_G_NORM_L0_BOX, g.lam
+        d.g_u = ptr(_vec(g.u, dtype, n, "u"))
+    elif isinstance(g, NormLpPowerNonneg):
+        d.g_kind, d.g_lambda, d.g_p = L.BZ_G_NORM_LP_NONNEG, g.alpha, g.p
+    elif isinstance(g, NormLpPowerBox):
+        d.g_kind, d.g_lambda, d.g_p = L.BZ_G_NORM_LP_BOX, g.alpha, g.p
         d.g_u = ptr(_vec(g.u, dtype, n, "u"))
     elif isinstance(g, IndBox):
         d.g_kind = L.BZ_G_IND_BOX

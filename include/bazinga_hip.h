@@ -60,6 +60,8 @@ extern "C" {
 #define BZ_G_NORM_L1_BOX     3   /* src/proxoperators/normL1Box.jl:30-39              */
 #define BZ_G_IND_BOX         4   /* ProximalOperators.IndBox (test_nonconvex_qp.jl:15)*/
 #define BZ_G_NORM_L0_BOX     5   /* src/proxoperators/normL0Box.jl:33-58              */
+#define BZ_G_NORM_LP_NONNEG  6   /* alpha*sum x^p, x >= 0: normLpNonneg.jl:14-90      */
+#define BZ_G_NORM_LP_BOX     7   /* alpha*sum x^p, 0 <= x <= u: normLpBox.jl:11-97    */
 /* c: constraint map.  eval!(cx,c,x), jtprod!(jtv,c,x,v)                             */
 #define BZ_C_IDENTITY        0   /* test/definitions/identityFunction.jl:3-13         */
 #define BZ_C_DENSE_AFFINE    1   /* A x - b, demo/basispursuit.jl:38-49               */
@@ -106,8 +108,9 @@ typedef struct {
                                       f_b then holds b[f_rows] resp. q[n]                */
     int64_t     f_rows;
     /* g */
-    double      g_lambda;          /* NORM_L1*: lambda >= 0                           */
-    const void* g_u;               /* NORM_L1_BOX / NORM_L0_BOX: u[n] >= 0            */
+    double      g_lambda;          /* NORM_L1*, NORM_L0_BOX: lambda >= 0; NORM_LP_*: alpha */
+    double      g_p;               /* NORM_LP_*: exponent p in (0,1)                  */
+    const void* g_u;               /* NORM_L1_BOX / NORM_L0_BOX / NORM_LP_BOX: u[n] >= 0 */
     double      g_lo, g_hi;        /* IND_BOX scalar bounds                           */
     const void* g_lo_vec;          /* IND_BOX vector bounds (or NULL)                 */
     const void* g_hi_vec;

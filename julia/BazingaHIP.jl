@@ -26,7 +26,7 @@ Base.@kwdef mutable struct ProblemDesc
     n::Int64 = 0; ny::Int64 = 0
     f_q::Ptr{Cvoid} = C_NULL; f_b::Ptr{Cvoid} = C_NULL; f_grid_nx::Int64 = 0; f_grid_ny::Int64 = 0
     f_A::Ptr{Cvoid} = C_NULL; f_rows::Int64 = 0
-    g_lambda::Float64 = 0; g_u::Ptr{Cvoid} = C_NULL; g_lo::Float64 = 0; g_hi::Float64 = 0
+    g_lambda::Float64 = 0; g_p::Float64 = 0; g_u::Ptr{Cvoid} = C_NULL; g_lo::Float64 = 0; g_hi::Float64 = 0
     g_lo_vec::Ptr{Cvoid} = C_NULL; g_hi_vec::Ptr{Cvoid} = C_NULL
     c_A::Ptr{Cvoid} = C_NULL; c_b::Ptr{Cvoid} = C_NULL
     D_lo::Float64 = 0; D_hi::Float64 = 0; D_lo_vec::Ptr{Cvoid} = C_NULL; D_hi_vec::Ptr{Cvoid} = C_NULL
@@ -84,6 +84,9 @@ lower_g!(d, g::ProximalOperators.NormL1{<:Real}) = (d.g_kind = 1; d.g_lambda = g
 lower_g!(d, g::Bazinga.NormL1Nonneg) = (d.g_kind = 2; d.g_lambda = g.lambda)
 lower_g!(d, g::Bazinga.NormL1Box) = (d.g_kind = 3; d.g_lambda = g.lambda; d.g_u = pointer(g.u))
 lower_g!(d, g::ProximalOperators.IndBox{<:Real,<:Real}) = (d.g_kind = 4; d.g_lo = g.lb; d.g_hi = g.ub)
+lower_g!(d, g::Bazinga.NormL0Box) = (d.g_kind = 5; d.g_lambda = g.lambda; d.g_u = pointer(g.u))
+lower_g!(d, g::Bazinga.NormLpPowerNonneg) = (d.g_kind = 6; d.g_lambda = g.alpha; d.g_p = g.p)
+lower_g!(d, g::Bazinga.NormLpPowerBox) = (d.g_kind = 7; d.g_lambda = g.alpha; d.g_p = g.p; d.g_u = pointer(g.u))
 lower_g!(d, g) = error("BazingaHIP: g of type $(typeof(g)) is not lowered to the device")
 
 # c: any SmoothFunction whose eval!/jtprod! are the identity (e.g. test/definitions/identityFunction.jl)

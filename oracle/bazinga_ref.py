@@ -262,6 +262,90 @@ class NormL0Box:
         return T(self.lam) * _sum(nz.astype(x.dtype))
 
 
+def _solve_lp_quasi_norm(x, p, a, gamma, u=None):
+    """Vectorised transcription of solve_lp_quasi_norm_subproblem_nonneg / _box
+    (src/proxoperators/normLpNonneg.jl:44-84, normLpBox.jl:47-97): per element the same Newton
+    iteration with the same start, stopping rule (|dphi| <= 1e-12, at most 1000 steps) and the same
+    global-minimum tests; elements that have stopped are frozen."""
+    T = x.dtype.type
+    box = u is not None
+    alpha = T(a) * T(gamma)
+    p = T(p)
+    out = np.zeros_like(x)
+    ap = alpha * p
+    zbar = (T(1) / (ap * (T(1) - p))) ** (T(1) / (p - T(2)))
+    psi = zbar + ap * zbar ** (p - T(1))
+    act = (x > 0) & (psi < x)
+    if box:
+        act &= (u != 0)
+    if not np.any(act):
+        return out
+    xa = x[act]
+    z = np.full_like(xa, zbar + (T(0.1) if box else T(1)))
+    run = np.ones(xa.shape, bool)
+    for _ in range(1000):
+        dphi = z - xa + ap * z ** (p - T(1))
+        run &= ~(np.abs(dphi) <= 1e-12)
+        if not np.any(run):
+            break
+        ddphi = T(1) + ap * (p - T(1)) * z ** (p - T(2))
+        z = np.where(run, z - dphi / ddphi, z)
+    phi0 = T(0.5) * (xa * xa)
+    phiz = T(0.5) * (z - xa) ** 2 + alpha * z ** p
+    res = np.where(phi0 <= phiz, T(0), z)
+    if box:
+        ua = u[act]
+        phiu = T(0.5) * (ua - xa) ** 2 + alpha * ua ** p
+        over = (res != 0) & (z > ua)
+        res = np.where(over, np.where(phiu < phi0, ua, T(0)), res)
+    out[act] = res
+    return out
+
+
+class NormLpPowerNonneg:
+    """src/proxoperators/normLpNonneg.jl:14-40"""
+
+    def __init__(self, p, *, alpha=1.0):
+        if p <= 0:
+            raise ValueError("p must be positive")
+        if p >= 1:
+            raise ValueError("p must be smaller than one")
+        if alpha < 0:
+            raise ValueError("alpha must be nonnegative")
+        self.p, self.alpha = p, alpha
+
+    def __call__(self, x):
+        return self.alpha * np.sum(x ** self.p)
+
+    def prox(self, y, x, gamma):
+        T = x.dtype.type
+        y[...] = _solve_lp_quasi_norm(x, self.p, self.alpha, gamma)
+        return T(self.alpha) * _sum(y ** T(self.p))
+
+
+class NormLpPowerBox:
+    """src/proxoperators/normLpBox.jl:11-45"""
+
+    def __init__(self, p, alpha=1.0, *, u):
+        if p <= 0:
+            raise ValueError("p must be positive")
+        if p >= 1:
+            raise ValueError("p must be smaller than one")
+        if alpha < 0:
+            raise ValueError("alpha must be nonnegative")
+        if np.any(np.asarray(u) < 0):
+            raise ValueError("vector u must have nonnegative entries")
+        self.p, self.alpha, self.u = p, alpha, np.asarray(u)
+
+    def __call__(self, x):
+        return self.alpha * np.sum(x ** self.p)
+
+    def prox(self, y, x, gamma):
+        T = x.dtype.type
+        y[...] = _solve_lp_quasi_norm(x, self.p, self.alpha, gamma, self.u.astype(x.dtype, copy=False))
+        return T(self.alpha) * _sum(y ** T(self.p))
+
+
 class IndBox:
     """ProximalOperators.IndBox(lb, ub) (test_nonconvex_qp.jl:15): prox = clamp,
     value 0.  lb/ub scalar or array."""

@@ -27,6 +27,11 @@ def make_cfg2(bz, ref, n, seed_start=0, D="box", dtype=np.float64, g="l1"):
     elif g == "l0box":
         u = np.where(np.arange(n) % 7 == 0, 0.0, 0.6).astype(dtype)
         g_d, g_r = bz.NormL0Box(0.3, u=u), ref.NormL0Box(0.3, u=u)
+    elif g == "lpnonneg":
+        g_d, g_r = bz.NormLpPowerNonneg(0.5, alpha=0.8), ref.NormLpPowerNonneg(dtype(0.5), alpha=dtype(0.8))
+    elif g == "lpbox":
+        u = np.where(np.arange(n) % 5 == 0, 0.0, 0.9).astype(dtype)
+        g_d, g_r = bz.NormLpPowerBox(0.5, 0.8, u=u), ref.NormLpPowerBox(dtype(0.5), dtype(0.8), u=u)
     elif g == "indbox":
         g_d, g_r = bz.IndBox(-0.5, 0.5), ref.IndBox(dtype(-0.5), dtype(0.5))
     else:
@@ -633,3 +638,34 @@ def test_headline_size_iterates_match_oracle(bz, ref):
     assert sum(r[7] for r in rows) >= 5
     p = prob.profile()
     prob.close()
+
+
+@pytest.mark.parametrize("g", ["lpnonneg", "lpbox"])
+def test_lp_power_prox(bz, ref, g):
+    """src/proxoperators/normLpNonneg.jl / normLpBox.jl: scalar Newton solve per element.  pow() is not
+    correctly rounded on either side, so z agrees to 1e-10 instead of bit for bit; the zero pattern
+    (the discrete decisions of the global-minimum tests) must agree except within rounding of a tie."""
+    n = 40001
+    d, dev, orc = make_cfg2(bz, ref, n, g=g)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(n) * 2
+    prob = bz.Problem(*dev, n, n, np.float64)
+    for gamma in (0.37, 1.9):
+        z_dev, gz_dev = prob.eval_prox(x, gamma)
+        z_ref = np.empty(n)
+        gz_ref = orc[1].prox(z_ref, x, gamma)
+        same_support = (z_dev != 0) == (z_ref != 0)
+        assert np.mean(same_support) >= 0.9999
+        m = same_support
+        assert np.max(np.abs(z_dev[m] - z_ref[m])) <= 1e-10
+        assert abs(gz_dev - gz_ref) <= 1e-6 * max(1.0, abs(gz_ref))
+        assert np.all(z_dev >= 0)
+    prob.close()
+    # a full (nonconvex) ALPS solve ends at a stationary point of the same quality as the oracle's
+    n = 3000
+    d, dev, orc = make_cfg2(bz, ref, n, g=g)
+    a = bz.alps(*dev, np.zeros(n), np.zeros(n))
+    o = ref.alps(*orc, np.zeros(n), np.zeros(n))
+    assert a[5] == o[5]
+    obj = lambda x: np.sum(x * (0.5 * d["q"] * x - d["b"])) + 0.8 * np.sum(np.maximum(x, 0) ** 0.5)
+    assert abs(obj(a[0]) - obj(o[0])) <= 1e-6 * max(1.0, abs(obj(o[0])))

@@ -65,8 +65,8 @@ int bz_ctx_create(const bz_ctx_opts* o, bz_ctx** out) {
             BZ_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
             // nranks == 1 with a comm_id builds a 1-rank communicator: exercises the all-gather
             // plumbing on a single GPU (tests)
-            if (o->nranks > 1 || o->comm_id) {
-                need(o->comm_id, "comm_id");
+            // nranks > 1 without a comm_id: the caller will connect the p2p mailboxes instead of RCCL
+            if (o->comm_id) {
                 ncclUniqueId id;
                 std::memcpy(&id, o->comm_id, sizeof(id));
                 BZ_NCCL(ncclCommInitRank(&c->c.comm, o->nranks, id, o->rank));
@@ -83,6 +83,13 @@ void bz_ctx_destroy(bz_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->c.device);
     delete ctx;
+}
+
+int bz_ctx_p2p_export(bz_ctx* ctx, void* handle64) {
+    return guard([&] { need(ctx, "ctx"); need(handle64, "handle64"); bz::p2p_export(&ctx->c, handle64); });
+}
+int bz_ctx_p2p_connect(bz_ctx* ctx, const void* handles, const int32_t* devices) {
+    return guard([&] { need(ctx, "ctx"); need(handles, "handles"); bz::p2p_connect(&ctx->c, handles, devices); });
 }
 
 int bz_device_info(bz_ctx* ctx, char* name256, int32_t* cus, int64_t* mem_bytes) {

@@ -707,6 +707,80 @@ k_gemv_t_finish(const T* __restrict__ part, int nchunks, int64_t pstride, const 
 //   traffic: res + s_1 + 2(m-1) + 1 + 2(m-1) + d_out = 4m passes   vs  8m-3 for the kernel chain.
 // The arithmetic per element and the coefficient formulas are those of k_dot / k_axpy_dot.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Peer-to-peer scalar exchange (one node, x sharded over the GPUs): system-scope 8-byte stores into
+// every rank's mailbox (fine-grained device memory mapped through HIP IPC), data first, then a
+// release fence, then a sequence-number flag; readers poll their OWN mailbox.  Double-buffered by the
+// parity of the sequence number: a rank can run at most one exchange ahead of the slowest rank,
+// because completing exchange q+1 needs everybody's q+1 contribution.
+// ---------------------------------------------------------------------------
+struct P2PWords {            // device view of bz::P2PMailbox (bz_solver.h); same layout
+    double pval[2][8];
+    unsigned long long pflag[2][8];
+    double xval[2][8][16];
+    unsigned long long xflag[2][8];
+};
+__device__ __forceinline__ void sys_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double sys_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr unsigned XSPIN_LIMIT = 20000000u;
+
+// fold this rank's block partials of slots [first, first+cnt), exchange the pack with all ranks and
+// leave every rank's pack in recv[r*cnt + i] (the layout ScalarSrc{recv, nranks, cnt} expects)
+struct XchgArgs {
+    const double* parts;
+    int counts[16];          // valid block partials per slot
+    int first, cnt;
+    unsigned maxmask;
+    int rank, nranks;
+    unsigned long long seq;
+    double* recv;
+    P2PWords* mbox_local;
+    P2PWords* mbox_peer[8];
+    int* timeout;
+};
+static __global__ void __launch_bounds__(BLOCK) k_exchange(XchgArgs a) {
+    __shared__ double sh[WAVES];
+    __shared__ double vals[16];
+    for (int i = 0; i < a.cnt; ++i) {
+        ScalarSrc s{a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts[i], 1};
+        const double t = fold_src(s, (a.maxmask >> i) & 1u, sh);
+        if (threadIdx.x == 0) vals[i] = t;
+    }
+    __syncthreads();
+    const int par = (int)(a.seq & 1ull);
+    const int tid = threadIdx.x;
+    if (tid < a.nranks * a.cnt) {
+        const int r = tid / a.cnt, i = tid % a.cnt;
+        sys_store(&a.mbox_peer[r]->xval[par][a.rank][i], vals[i]);
+    }
+    __threadfence_system();          // every storing lane: data before flag
+    __syncthreads();
+    if (tid < a.nranks) sys_store(&a.mbox_peer[tid]->xflag[par][a.rank], a.seq);
+    if (tid < a.nranks) {
+        unsigned spins = 0;
+        while (sys_load(&a.mbox_local->xflag[par][tid]) < a.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > XSPIN_LIMIT) { *a.timeout = 2; break; }
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < a.nranks * a.cnt) {
+        const int r = tid / a.cnt, i = tid % a.cnt;
+        a.recv[r * a.cnt + i] = sys_load(&a.mbox_local->xval[par][r][i]);
+    }
+}
+
 constexpr int PBLOCK = 512;
 constexpr int PWAVES = PBLOCK / 64;
 constexpr int PMAXMEM = 16;
@@ -728,6 +802,14 @@ template <class T> struct PersistArgs {
     unsigned long long base; // counter value when this launch starts
     int* timeout;            // host-visible flag, set if a spin gives up
     int slot_loop1, slot_loop2;
+    // multi-GPU (x sharded): phase totals are exchanged through the peers' mailboxes
+    int nranks, rank;
+    unsigned long long pseq; // sequence number of this launch's first phase
+    P2PWords* mbox_local;
+    P2PWords* mbox_peer[8];
+    double* gtot;            // [2] global total of the current phase, published by block 0
+    unsigned long long* gflag;
+    double* final_tot;       // global <y_0, d> for the kernel that fuses the last axpy
 };
 
 __device__ __forceinline__ double block_sum512(double v, double* sh) {
@@ -794,6 +876,56 @@ __device__ __forceinline__ double grid_wait_fold(double* row, int nb, unsigned l
     return block_sum512(v, sh);
 }
 
+// Multi-GPU form of the phase boundary.  Block 0 waits for the local arrivals, folds the local
+// partials, exchanges the rank totals through the mailboxes (rank-ordered sum -> identical bits on all
+// ranks) and publishes the global total locally; the other blocks only wait for that publication.
+template <class A>
+__device__ __forceinline__ double grid_wait_fold_multi(const A& a, double* row, unsigned long long target,
+                                                       unsigned long long q, double* sh) {
+    const int par = (int)(q & 1ull);
+    __shared__ double gsh;
+    if (blockIdx.x == 0) {
+        const double local = grid_wait_fold(row, a.nb, a.counter, target, a.timeout, sh);
+        const int tid = threadIdx.x;
+        if (tid < a.nranks) sys_store(&a.mbox_peer[tid]->pval[par][a.rank], local);
+        __threadfence_system();
+        __syncthreads();
+        if (tid < a.nranks) sys_store(&a.mbox_peer[tid]->pflag[par][a.rank], q);
+        if (tid < a.nranks) {
+            unsigned spins = 0;
+            while (sys_load(&a.mbox_local->pflag[par][tid]) < q) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > XSPIN_LIMIT) { *a.timeout = 3; break; }
+            }
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            double g = 0.0;
+            for (int r = 0; r < a.nranks; ++r) g += sys_load(&a.mbox_local->pval[par][r]);
+            gsh = g;
+            __hip_atomic_store(a.gtot + par, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.gflag, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        return gsh;
+    }
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.gflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > PSPIN_LIMIT) { *a.timeout = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        gsh = __hip_atomic_load(a.gtot + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const double g = gsh;
+    __syncthreads();
+    return g;
+}
+
 // Stream KR rounds of one or two vectors past the register-resident d with an explicit two-deep
 // software pipeline: the loads of the next group of G rounds are issued before the current group
 // is consumed, and sched_barriers keep the compiler from sinking them back to their uses (with d
@@ -856,6 +988,13 @@ k_twoloop_persist(PersistArgs<T> a) {
     __syncthreads();
     Pack<T> d[KR];
     unsigned long long target = a.base;
+    unsigned long long q = a.pseq;          // multi-GPU: sequence number of the coming phase
+    auto phase_total = [&](double* row) -> double {
+        if (a.nranks <= 1) return grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
+        const double g = grid_wait_fold_multi(a, row, target, q, sh);
+        ++q;
+        return g;
+    };
     const int64_t first = ((int64_t)blockIdx.x * PBLOCK + threadIdx.x) * N;
 
     // Per phase the element stride between a thread's packs is re-read from LDS through a volatile
@@ -887,7 +1026,7 @@ k_twoloop_persist(PersistArgs<T> a) {
         target += nb;
         grid_arrive(acc, row, a.counter, sh);
         persist_prefetch<T, G, true>(a.Y[j], a.S[j + 1], first, BZ_P_STRIDE, pv, pw);
-        const double tot = grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
+        const double tot = phase_total(row);
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
         const T coef = -al;
@@ -910,7 +1049,7 @@ k_twoloop_persist(PersistArgs<T> a) {
         target += nb;
         grid_arrive(acc, row, a.counter, sh);
         persist_prefetch<T, G, false>(a.Y[j], a.Y[j], first, BZ_P_STRIDE, pv, pw);
-        const double tot = grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
+        const double tot = phase_total(row);
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
         const T coef = -al;
@@ -935,7 +1074,7 @@ k_twoloop_persist(PersistArgs<T> a) {
         target += nb;
         grid_arrive(acc, row, a.counter, sh);
         persist_prefetch<T, G, true>(a.S[j], a.Y[j - 1], first, BZ_P_STRIDE, pv, pw);
-        const double tot = grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
+        const double tot = phase_total(row);
         const T beta = T(tot) / a.ys[j];
         const T coef = alpha_sh[j] - beta;
         acc = 0.0;
@@ -950,8 +1089,16 @@ k_twoloop_persist(PersistArgs<T> a) {
                 }
             });
     }
-    // last partial (<y_0, d>) and d go to memory: the next kernel fuses the final axpy
-    {
+    // last partial (<y_0, d>) and d go to memory: the next kernel fuses the final axpy.  On several GPUs
+    // one more phase turns the partials into the global total (the consumer cannot fold across ranks).
+    if (a.nranks > 1) {
+        double* row = a.parts + (size_t)(a.slot_loop2 + 0) * PSTRIDE;
+        target += nb;
+        grid_arrive(acc, row, a.counter, sh);
+        const double tot = phase_total(row);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.final_tot = tot;
+        if (blockIdx.x == 0 && threadIdx.x < m) a.alphas[threadIdx.x] = (double)alpha_sh[threadIdx.x];
+    } else {
         const double part = block_sum512(acc, sh);
         if (threadIdx.x == 0) a.parts[(size_t)(a.slot_loop2 + 0) * PSTRIDE + blockIdx.x] = part;
         if (blockIdx.x == 0 && threadIdx.x < m) a.alphas[threadIdx.x] = (double)alpha_sh[threadIdx.x];

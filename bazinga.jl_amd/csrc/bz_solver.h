@@ -38,10 +38,28 @@ struct Error : std::runtime_error {
             throw ::bz::Error(BZ_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
     } while (0)
 
+// Peer-to-peer scalar mailbox (single node): every rank owns a small fine-grained device buffer that all
+// ranks map through HIP IPC; scalars are exchanged by system-scope stores straight into the peers'
+// mailboxes over xGMI, tagged with a sequence number — no collective library call, no host involvement.
+constexpr int P2P_MAXRANKS = 8;
+constexpr int P2P_PACK = 16;               // doubles per pack exchange
+struct P2PMailbox {                        // layout of one rank's mailbox (all words written by peers)
+    double pval[2][P2P_MAXRANKS];                          // persistent-kernel phase totals
+    unsigned long long pflag[2][P2P_MAXRANKS];
+    double xval[2][P2P_MAXRANKS][P2P_PACK];                // pack exchanges (k_exchange)
+    unsigned long long xflag[2][P2P_MAXRANKS];
+};
 struct Ctx {
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
+    // p2p
+    bool p2p_on = false;
+    P2PMailbox* mbox_local = nullptr;
+    P2PMailbox* mbox_peer[P2P_MAXRANKS] = {};
+    bool mbox_opened[P2P_MAXRANKS] = {};
+    unsigned long long pseq = 0, xseq = 0;  // sequence numbers, identical on all ranks by construction
+    bool multi() const { return comm != nullptr || p2p_on; }
     ~Ctx();
 };
 
@@ -102,6 +120,9 @@ struct SolverBase {
     virtual void profile_get(int cat, int64_t* launches, double* ms) = 0;
     virtual void profile_reset() = 0;
 };
+
+void p2p_export(Ctx* ctx, void* handle64);
+void p2p_connect(Ctx* ctx, const void* handles, const int32_t* devices);
 
 SolverBase* make_solver(Ctx* ctx, const bz_problem_desc& d);
 

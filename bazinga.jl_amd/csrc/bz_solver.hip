@@ -22,8 +22,54 @@
 namespace bz {
 
 Ctx::~Ctx() {
+    for (int r = 0; r < P2P_MAXRANKS; ++r)
+        if (mbox_opened[r] && mbox_peer[r]) (void)hipIpcCloseMemHandle(mbox_peer[r]);
+    if (mbox_local) (void)hipFree(mbox_local);
     if (comm) (void)ncclCommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
+}
+
+static_assert(sizeof(P2PMailbox) == sizeof(P2PWords), "host and device mailbox layouts differ");
+
+// allocate this rank's mailbox (fine-grained: peers' system-scope stores must be visible to a running
+// kernel) and hand out its IPC handle
+void p2p_export(Ctx* ctx, void* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle is 64 bytes");
+    if (ctx->nranks > P2P_MAXRANKS) throw Error(BZ_ERR_ARG, "p2p supports at most 8 ranks");
+    BZ_HIP(hipSetDevice(ctx->device));
+    if (!ctx->mbox_local) {
+        void* p = nullptr;
+        BZ_HIP(hipExtMallocWithFlags(&p, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
+        BZ_HIP(hipMemset(p, 0, sizeof(P2PMailbox)));
+        BZ_HIP(hipDeviceSynchronize());
+        ctx->mbox_local = (P2PMailbox*)p;
+    }
+    hipIpcMemHandle_t h;
+    BZ_HIP(hipIpcGetMemHandle(&h, ctx->mbox_local));
+    std::memcpy(handle64, &h, sizeof(h));
+}
+
+// map every rank's mailbox; from here on scalar exchanges bypass RCCL
+void p2p_connect(Ctx* ctx, const void* handles, const int32_t* devices) {
+    if (!ctx->mbox_local) throw Error(BZ_ERR_STATE, "bz_ctx_p2p_export must be called first");
+    BZ_HIP(hipSetDevice(ctx->device));
+    const unsigned char* hs = (const unsigned char*)handles;
+    for (int r = 0; r < ctx->nranks; ++r) {
+        if (r == ctx->rank) { ctx->mbox_peer[r] = ctx->mbox_local; continue; }
+        if (devices && devices[r] != ctx->device) {
+            hipError_t e = hipDeviceEnablePeerAccess(devices[r], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                throw Error(BZ_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, hs + (size_t)r * 64, 64);
+        void* p = nullptr;
+        BZ_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        ctx->mbox_peer[r] = (P2PMailbox*)p;
+        ctx->mbox_opened[r] = true;
+    }
+    ctx->p2p_on = true;
 }
 
 // ---------------------------------------------------------------------------
@@ -91,12 +137,15 @@ template <class T> class Solver final : public SolverBase {
             hipDeviceProp_t prop;
             BZ_HIP(hipGetDeviceProperties(&prop, ctx->device));
             num_cus = prop.multiProcessorCount;
+            pblocks = num_cus;
+            // BZ_PERSIST_BLOCKS: run the persistent kernel on fewer CUs (two ranks sharing one GPU in tests)
+            if (const char* e = getenv("BZ_PERSIST_BLOCKS")) pblocks = std::max(1, std::min(num_cus, atoi(e)));
             // persistent two-loop: one 512-thread block per CU, KR register packs per thread; its vectors
             // are zero-padded to KR*num_cus*512 packs so that every round is in-bounds (no masks)
-            const int64_t kneed = (nchunks + (int64_t)num_cus * PBLOCK - 1) / ((int64_t)num_cus * PBLOCK);
-            persist_kr = (kneed <= 40 && num_cus > 0 && num_cus <= PSTRIDE) ? (int)(4 * ((kneed + 3) / 4)) : 0;
+            const int64_t kneed = (nchunks + (int64_t)pblocks * PBLOCK - 1) / ((int64_t)pblocks * PBLOCK);
+            persist_kr = (kneed <= 40 && pblocks > 0 && pblocks <= PSTRIDE) ? (int)(4 * ((kneed + 3) / 4)) : 0;
             vcap = n;
-            if (persist_kr) vcap = std::max<int64_t>(n, (int64_t)persist_kr * num_cus * PBLOCK * PackN<T>::N);
+            if (persist_kr) vcap = std::max<int64_t>(n, (int64_t)persist_kr * pblocks * PBLOCK * PackN<T>::N);
         }
         int g = (int)std::min<int64_t>(PSTRIDE, std::max<int64_t>(1, (nchunks + BLOCK - 1) / BLOCK));
         if (const char* e = getenv("BZ_GRID")) g = std::max(1, std::min(PSTRIDE, atoi(e)));
@@ -181,6 +230,7 @@ template <class T> class Solver final : public SolverBase {
         *ptimeout_ = 0;
         BZ_HIP(hipHostGetDevicePointer((void**)&ptimeout_dev_, ptimeout_, 0));
         pcounter_.alloc(PSHARDS * PSHARD_STRIDE);      // zero-filled by alloc
+        pgflag_.alloc(2); pglobal_.alloc(4);
         for (int s = 0; s < SL_COUNT; ++s) { grp_first[s] = s; grp_cnt[s] = 1; slot_n[s] = grid; }
         slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
         BZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -409,7 +459,9 @@ template <class T> class Solver final : public SolverBase {
     int f_rows_per_chunk = 1, f_nrowchunks = 1;
     T fscale = T(1);                         // f(x) = fscale * (sum of the f partials)
     // persistent two-loop
-    DBuf<unsigned long long> pcounter_;
+    DBuf<unsigned long long> pcounter_, pgflag_;
+    DBuf<double> pglobal_;                   // [0..1] phase totals (double-buffered), [2] final <y_0,d>
+    int pblocks = 0;                         // blocks of the persistent grid (= CUs unless overridden)
     unsigned long long pbase = 0;
     int* ptimeout_ = nullptr;                // host-mapped
     int* ptimeout_dev_ = nullptr;
@@ -513,14 +565,29 @@ template <class T> class Solver final : public SolverBase {
 
     // multi-GPU: fold this rank's block partials of slots [first, first+cnt) and all-gather
     void gather(int first, int cnt, unsigned maxmask) {
-        if (!ctx->comm) return;
+        if (!ctx->multi()) return;
+        if (ctx->p2p_on) {
+            if (cnt > P2P_PACK) throw Error(BZ_ERR_ARG, "pack too large for the p2p mailbox");
+            XchgArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.parts = parts_.p; a.first = first; a.cnt = cnt; a.maxmask = maxmask;
+            for (int i = 0; i < cnt; ++i) a.counts[i] = slot_n[first + i];
+            a.rank = ctx->rank; a.nranks = ctx->nranks; a.seq = ++ctx->xseq;
+            a.recv = recv_.p + (size_t)first * ctx->nranks;
+            a.mbox_local = (P2PWords*)ctx->mbox_local;
+            for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
+            a.timeout = ptimeout_dev_;
+            launch(C_GATHER, k_exchange, 1, a);
+            for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
+            return;
+        }
         launch(C_GATHER, k_pack, 1, (const double*)parts_.p, grid, first, cnt, maxmask, send_.p);
         BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
                               ctx->comm, ctx->stream));
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
     }
     ScalarSrc src(int slot) const {
-        if (!ctx->comm) return ScalarSrc{parts_.p + (size_t)slot * PSTRIDE, slot_n[slot], 1};
+        if (!ctx->multi()) return ScalarSrc{parts_.p + (size_t)slot * PSTRIDE, slot_n[slot], 1};
         const int f = grp_first[slot], c = grp_cnt[slot];
         return ScalarSrc{recv_.p + (size_t)f * ctx->nranks + (slot - f), ctx->nranks, c};
     }
@@ -535,8 +602,12 @@ template <class T> class Solver final : public SolverBase {
         launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
         BZ_HIP(hipStreamSynchronize(ctx->stream));
         if (*ptimeout_) {
+            const int code = *ptimeout_;
             *ptimeout_ = 0;
-            throw Error(BZ_ERR_HIP, "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)");
+            throw Error(code == 1 ? BZ_ERR_HIP : BZ_ERR_COMM,
+                        code == 1 ? "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)"
+                        : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
+                                    : "persistent two-loop kernel: p2p phase exchange timed out waiting for a peer rank");
         }
         return std::vector<double>(host_out_, host_out_ + a.n);
     }
@@ -699,10 +770,20 @@ template <class T> class Solver final : public SolverBase {
         std::memset(&a, 0, sizeof(a));
         a.res = RES_[rc].p;
         for (int j = 0; j < m; ++j) { a.S[j] = S_[order[j]].p; a.Y[j] = Y_[order[j]].p; a.ys[j] = ys_[order[j]]; }
-        a.H = H; a.m = m; a.nb = num_cus; a.d_out = D_.p; a.n = n; a.parts = parts_.p; a.alphas = alphas_.p;
+        a.H = H; a.m = m; a.d_out = D_.p; a.n = n; a.parts = parts_.p; a.alphas = alphas_.p;
         a.counter = pcounter_.p; a.base = pbase; a.timeout = ptimeout_dev_;
         a.slot_loop1 = SL_LOOP1; a.slot_loop2 = SL_LOOP2;
-        pbase += (unsigned long long)(2 * m - 1) * num_cus;
+        a.nb = persist_blocks();
+        const bool multi = ctx->nranks > 1;
+        const int nphases = 2 * m - 1 + (multi ? 1 : 0);
+        a.nranks = ctx->nranks; a.rank = ctx->rank; a.pseq = ctx->pseq + 1;
+        if (multi) {
+            a.mbox_local = (P2PWords*)ctx->mbox_local;
+            for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
+            a.gtot = pglobal_.p; a.gflag = pgflag_.p; a.final_tot = pglobal_.p + 2;
+            ctx->pseq += nphases;
+        }
+        pbase += (unsigned long long)nphases * a.nb;
         switch (persist_kr) {
         case 4: launch_persist(k_twoloop_persist<T, 4>, a); break;
         case 8: launch_persist(k_twoloop_persist<T, 8>, a); break;
@@ -715,19 +796,21 @@ template <class T> class Solver final : public SolverBase {
         case 36: launch_persist(k_twoloop_persist<T, 36>, a); break;
         default: launch_persist(k_twoloop_persist<T, 40>, a); break;
         }
-        slot_n[SL_LOOP2 + 0] = num_cus;
+        slot_n[SL_LOOP2 + 0] = a.nb;
         t.in = D_.p; t.sgn = T(1); t.v = S_[order[0]].p; t.mode = 1; t.j = 0; t.apply_H = 0; t.H = T(1);
-        t.src = src(SL_LOOP2 + 0); t.ys = ys_[order[0]];
+        t.src = multi ? ScalarSrc{pglobal_.p + 2, 1, 1} : src(SL_LOOP2 + 0);
+        t.ys = ys_[order[0]];
         return t;
     }
+    int persist_blocks() const { return pblocks; }
     template <class K> void launch_persist(K kernel, const PersistArgs<T>& a) {
         ProfRec r{C_PERSIST, nullptr, nullptr};
         if ((prof_mask >> C_PERSIST) & 1u) {
             r.a = get_event(); r.b = get_event();
-            hipExtLaunchKernelGGL(kernel, dim3(num_cus), dim3(PBLOCK), 0, ctx->stream, r.a, r.b, 0, a);
+            hipExtLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, ctx->stream, r.a, r.b, 0, a);
             prof_recs.push_back(r);
         } else {
-            hipLaunchKernelGGL(kernel, dim3(num_cus), dim3(PBLOCK), 0, ctx->stream, a);
+            hipLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, ctx->stream, a);
         }
         BZ_HIP(hipGetLastError());
     }
@@ -795,7 +878,10 @@ template <class T> class Solver final : public SolverBase {
             // block per CU) and the vector must be long enough for 2m-1 grid barriers to beat 2m launches
             int64_t min_n = 300000;      // below this 2m short launches beat 2m-1 grid barriers (~5 us each)
             if (const char* e = getenv("BZ_PERSIST_MIN_N")) min_n = atoll(e);
-            persist_ok = o.persist && !ctx->comm && persist_kr > 0 && n >= min_n;
+            // with several ranks the phases need the p2p mailboxes (RCCL cannot be called from a kernel)
+            persist_ok = o.persist && (!ctx->multi() || ctx->p2p_on) && persist_kr > 0 && n >= min_n;
+            if (ctx->nranks > 1 && !ctx->multi())
+                throw Error(BZ_ERR_STATE, "nranks > 1 needs an RCCL communicator or connected p2p mailboxes");
         }
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;

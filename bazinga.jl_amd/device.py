@@ -21,8 +21,8 @@ class Context:
         o = L.CtxOpts()
         o.device, o.rank, o.nranks = device, rank, nranks
         self._id = None
-        if nranks > 1 and (comm_id is None or len(comm_id) != 128):
-            raise ValueError("nranks > 1 needs the 128-byte id from unique_id() on rank 0")
+        if comm_id is not None and len(comm_id) != 128:
+            raise ValueError("comm_id must be the 128-byte id from unique_id() on rank 0")
         if comm_id is not None:
             self._id = C.create_string_buffer(comm_id, 128)
             o.comm_id = C.cast(self._id, C.c_void_p)
@@ -36,6 +36,18 @@ class Context:
         buf = C.create_string_buffer(128)
         L.check(L.load().bz_comm_unique_id(buf))
         return buf.raw
+
+    def p2p_export(self) -> bytes:
+        """This rank's mailbox IPC handle (64 bytes); all-gather them, then p2p_connect."""
+        buf = C.create_string_buffer(64)
+        L.check(L.load().bz_ctx_p2p_export(self._h, buf))
+        return buf.raw
+
+    def p2p_connect(self, handles, devices):
+        """handles: list of nranks 64-byte handles in rank order; devices: HIP ordinal of every rank."""
+        blob = C.create_string_buffer(b"".join(handles), 64 * self.nranks)
+        dev = (C.c_int32 * self.nranks)(*devices)
+        L.check(L.load().bz_ctx_p2p_connect(self._h, blob, dev))
 
     def info(self):
         name = C.create_string_buffer(256)

@@ -79,13 +79,19 @@ typedef struct {
     int32_t rank;         /* this rank, 0..nranks-1                                  */
     int32_t nranks;       /* 1 = single GPU; >1 = x sharded, scalars all-gathered    */
     int32_t reserved;
-    const void* comm_id;  /* nranks>1: 128-byte id from bz_comm_unique_id on rank 0
-                             (nranks==1 + id: 1-rank communicator, for testing)      */
+    const void* comm_id;  /* 128-byte id from bz_comm_unique_id on rank 0: RCCL communicator
+                             (nranks==1 + id: 1-rank communicator, for testing; NULL with
+                             nranks>1: p2p mailboxes must be connected instead)        */
 } bz_ctx_opts;
 
 int  bz_comm_unique_id(void* id128);                 /* fills 128 bytes (RCCL id)     */
 int  bz_ctx_create(const bz_ctx_opts* opts, bz_ctx** out);
 void bz_ctx_destroy(bz_ctx* ctx);
+/* Peer-to-peer scalar mailboxes (single node, optional; replaces the RCCL all-gather and lets the
+ * persistent two-loop kernel run sharded): every rank exports the 64-byte HIP IPC handle of its
+ * mailbox, the launcher all-gathers the handles and the device ordinals, every rank connects.      */
+int  bz_ctx_p2p_export(bz_ctx* ctx, void* handle64);
+int  bz_ctx_p2p_connect(bz_ctx* ctx, const void* handles /* nranks*64 bytes */, const int32_t* devices);
 const char* bz_last_error(void);
 const char* bz_version(void);
 /* fills name (<=255 chars), compute-unit count and total device memory in bytes */

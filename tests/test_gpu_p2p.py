@@ -1,0 +1,94 @@
+"""Multi-rank path on ONE GPU: two processes share device 0, x is sharded between them and every global
+scalar travels through the peer-to-peer mailboxes (HIP IPC + system-scope stores), including the phases
+INSIDE the persistent two-loop kernel (each rank runs it on half of the CUs so both grids are
+co-resident).  Exercises everything of the N > 1 design except a physical xGMI hop; the result must
+match the single-rank solve of the unsharded problem."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_TOTAL = 800_000
+ITERS = 14
+
+
+def _worker(rank, world, n_total, persist, conn):
+    try:
+        os.environ["BZ_PERSIST_BLOCKS"] = "96"
+        sys.path.insert(0, ROOT)
+        import bazinga_jl_amd as bz
+        ctx = bz.Context(device=0, rank=rank, nranks=world, comm_id=None)
+        conn.send(ctx.p2p_export())
+        handles = conn.recv()
+        ctx.p2p_connect(handles, [0] * world)
+        lo, hi = bz.shard_bounds(n_total, rank, world)
+        d = bz.synth.l1_quadratic(hi - lo, start=lo)
+        nl = hi - lo
+        prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                          bz.ClosedSet(bz.IndBox(-1.0, 1.0)), nl, nl, np.float64, ctx)
+        y = np.sin(np.arange(lo, hi, dtype=np.float64))
+        prob.set_multipliers(np.full(nl, 0.1), y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist).c_opts(), np.zeros(nl))
+        prob.profile_enable(True)
+        for _ in range(ITERS):
+            prob.panoc_step()
+        prof = prob.profile()
+        out = (rank, lo, hi, prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(),
+               prof["k_twoloop_persist"]["launches"], prof["all_gather"]["launches"])
+        prob.close()
+        ctx.close()
+        conn.send(("ok", out))
+    except Exception as e:      # noqa: BLE001
+        conn.send(("error", repr(e)))
+
+
+def _run_sharded(world, persist):
+    mpc = mp.get_context("spawn")
+    pipes = [mpc.Pipe() for _ in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, N_TOTAL, persist, pipes[r][1])) for r in range(world)]
+    for p in procs:
+        p.start()
+    handles = [pipes[r][0].recv() for r in range(world)]
+    for r in range(world):
+        pipes[r][0].send(handles)
+    res = []
+    for r in range(world):
+        assert pipes[r][0].poll(240), "rank did not answer"
+        status, payload = pipes[r][0].recv()
+        assert status == "ok", payload
+        res.append(payload)
+    for p in procs:
+        p.join(60)
+    return sorted(res)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("persist", [False, True])
+def test_two_ranks_on_one_gpu_match_single_rank(bz, persist):
+    res = _run_sharded(2, persist)
+    d = bz.synth.l1_quadratic(N_TOTAL)
+    prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                      bz.ClosedSet(bz.IndBox(-1.0, 1.0)), N_TOTAL, N_TOTAL, np.float64)
+    prob.set_multipliers(np.full(N_TOTAL, 0.1), np.sin(np.arange(N_TOTAL, dtype=np.float64)))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(N_TOTAL))
+    for _ in range(ITERS):
+        prob.panoc_step()
+    x1, z1, s1 = prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars()
+    prob.close()
+    x = np.concatenate([r[3] for r in res])
+    z = np.concatenate([r[4] for r in res])
+    sa, sb = res[0][5], res[1][5]
+    for key in ("gamma", "f_x", "g_z", "stop_norm", "last_ys", "lbfgs_H", "FBE"):
+        assert sa[key] == sb[key], f"ranks disagree on {key}"          # bit-identical scalars on every rank
+    assert sa["gamma"] == s1["gamma"] and sa["lbfgs_mem"] == 5.0
+    assert np.max(np.abs(x - x1)) <= 1e-10 * np.max(np.abs(x1))
+    assert np.max(np.abs(z - z1)) <= 1e-10 * np.max(np.abs(z1))
+    assert abs(sa["stop_norm"] - s1["stop_norm"]) <= 1e-8 * max(1.0, s1["stop_norm"])
+    if persist:
+        assert all(r[6] >= ITERS - 2 for r in res)      # the persistent kernel really ran sharded
+    else:
+        assert all(r[6] == 0 and r[7] > 10 * ITERS for r in res)

@@ -91,4 +91,4 @@ def test_two_ranks_on_one_gpu_match_single_rank(bz, persist):
     if persist:
         assert all(r[6] >= ITERS - 2 for r in res)      # the persistent kernel really ran sharded
     else:
-        assert all(r[6] == 0 and r[7] > 10 * ITERS for r in res)
+        assert all(r[6] == 0 and r[7] > 5 * ITERS for r in res)

@@ -346,7 +346,11 @@ template <class T> class Solver final : public SolverBase {
         copy_out(d, D_.p, n);
     }
 
-    void profile_enable(unsigned mask) override { prof_mask = mask; }
+    void profile_enable(unsigned mask) override {
+        prof_mask = mask & 0xFFFFu;
+        prof_period = std::max(1u, mask >> 16);          // upper 16 bits: time every k-th launch only
+        for (auto& c : prof_count) c = 0;
+    }
     void profile_reset() override {
         drain_prof();
         for (int c = 0; c < BZ_NUM_KERNEL_CATEGORIES; ++c) { prof_ms[c] = 0; prof_n[c] = 0; }
@@ -497,7 +501,12 @@ template <class T> class Solver final : public SolverBase {
 
     // profiling
     struct ProfRec { int cat; hipEvent_t a, b; };
-    unsigned prof_mask = 0;
+    unsigned prof_mask = 0, prof_period = 1;
+    unsigned prof_count[BZ_NUM_KERNEL_CATEGORIES] = {0};
+    bool prof_pick(int cat) {
+        if (!((prof_mask >> cat) & 1u)) return false;
+        return (prof_count[cat]++ % prof_period) == 0;
+    }
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[BZ_NUM_KERNEL_CATEGORIES] = {0};
@@ -520,7 +529,7 @@ template <class T> class Solver final : public SolverBase {
 
     template <class K, class... A> void launch(int cat, K kernel, int g, A... args) {
         ProfRec r{cat, nullptr, nullptr};
-        const bool prof_on = (prof_mask >> cat) & 1u;
+        const bool prof_on = prof_pick(cat);
         if (prof_on) {
             // start/stop events bound to the dispatch itself: kernel time without the launch gap
             r.a = get_event(); r.b = get_event();
@@ -535,7 +544,7 @@ template <class T> class Solver final : public SolverBase {
 
     template <class K, class... A> void launch2d(int cat, K kernel, int gx, int gy, A... args) {
         ProfRec r{cat, nullptr, nullptr};
-        if ((prof_mask >> cat) & 1u) {
+        if (prof_pick(cat)) {
             r.a = get_event(); r.b = get_event();
             hipExtLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, ctx->stream, r.a, r.b, 0, args...);
             prof_recs.push_back(r);
@@ -805,7 +814,7 @@ template <class T> class Solver final : public SolverBase {
     int persist_blocks() const { return pblocks; }
     template <class K> void launch_persist(K kernel, const PersistArgs<T>& a) {
         ProfRec r{C_PERSIST, nullptr, nullptr};
-        if ((prof_mask >> C_PERSIST) & 1u) {
+        if (prof_pick(C_PERSIST)) {
             r.a = get_event(); r.b = get_event();
             hipExtLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, ctx->stream, r.a, r.b, 0, a);
             prof_recs.push_back(r);

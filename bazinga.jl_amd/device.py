@@ -184,10 +184,11 @@ class Problem:
                                        v.ctypes.data, d.ctypes.data))
         return d
 
-    def profile_enable(self, on=True):
-        """on: True (all categories), False, or a bitmask over _lib.KERNEL_CATEGORIES."""
-        mask = -1 if on is True else (0 if on is False else int(on))
-        L.check(L.load().bz_profile_enable(self._h, mask))
+    def profile_enable(self, on=True, period=1):
+        """on: True (all categories), False, or a bitmask over _lib.KERNEL_CATEGORIES;
+        period k: only every k-th launch of each enabled category is timed."""
+        mask = 0xFFFF if on is True else (0 if on is False else int(on) & 0xFFFF)
+        L.check(L.load().bz_profile_enable(self._h, mask | (int(period) << 16)))
 
     def profile_reset(self):
         L.check(L.load().bz_profile_reset(self._h))

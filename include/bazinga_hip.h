@@ -12,9 +12,10 @@
  * Conventions
  *  - plain pointers and sizes only; all vectors are dense, contiguous, of the
  *    problem's dtype (double for BZ_F64, float for BZ_F32);
- *  - unless a function says "device", pointers are HOST pointers; the library
- *    copies them and never writes through an input pointer (x0/y0 are never
- *    mutated — pinned by test/problems/test_nonconvex_qp.jl:36);
+ *  - input/output pointers may be host OR device pointers (copies use
+ *    hipMemcpyDefault); the library copies inputs into its own HBM buffers and
+ *    never writes through an input pointer (x0/y0 are never mutated — pinned by
+ *    test/problems/test_nonconvex_qp.jl:36);
  *  - every function returns BZ_OK (0) or a negative error code;
  *    bz_last_error() gives the message of the calling thread's last failure;
  *  - handles are not thread-safe; distinct handles are independent;
@@ -103,7 +104,7 @@ int  bz_device_info(bz_ctx* ctx, char* name256, int32_t* cus, int64_t* mem_bytes
 typedef struct {
     int32_t dtype;                 /* BZ_F64 | BZ_F32                                 */
     int32_t f_kind, g_kind, c_kind, D_kind;
-    int32_t data_on_device;        /* 1: pointers below are device pointers (copied)  */
+    int32_t data_on_device;        /* informational: pointers below may be host or device */
     int64_t n;                     /* length of x (local shard)                       */
     int64_t ny;                    /* length of y / c(x) (local shard)                */
     /* f */
@@ -240,7 +241,8 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
  *           2 AL gradient, 3 forward-backward step, 4 L-BFGS update/stop norm,
  *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot),
  *           9 dense GEMV kernels (vector ALU), 10 k_twoloop_persist, 11 k_gemv_t_mfma.
- * mask: bit c enables timing of category c (0 = off, -1 = all).                     */
+ * mask: bits 0..15: bit c enables timing of category c (0 = off); bits 16..31: sampling period k
+ *       (0/1 = every launch, k = every k-th launch of each enabled category).          */
 #define BZ_NUM_KERNEL_CATEGORIES 12
 int bz_profile_enable(bz_problem* p, int32_t mask);
 int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms);

@@ -32,7 +32,7 @@ class CtxOpts(C.Structure):
 class ProblemDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("f_kind", C.c_int32), ("g_kind", C.c_int32), ("c_kind", C.c_int32),
-        ("D_kind", C.c_int32), ("data_on_device", C.c_int32),
+        ("D_kind", C.c_int32), ("slack", C.c_int32),
         ("n", C.c_int64), ("ny", C.c_int64),
         ("f_q", C.c_void_p), ("f_b", C.c_void_p), ("f_grid_nx", C.c_int64), ("f_grid_ny", C.c_int64),
         ("f_A", C.c_void_p), ("f_rows", C.c_int64),
@@ -97,6 +97,7 @@ SIGNATURES = {
     "bz_panoc_vector": (C.c_int, [_vp, C.c_int32, _vp]),
     "bz_alps_default_opts": (None, [_P(AlpsOpts), C.c_int32]),
     "bz_alps_solve": (C.c_int, [_vp, _P(AlpsOpts), _P(PanocOpts), _vp, _vp, _vp, _vp, _vp, _vp, _P(AlpsStats)]),
+    "bz_als_solve": (C.c_int, [_vp, _P(AlpsOpts), _P(PanocOpts), _vp, _vp, _vp, _vp, _vp, _vp, _P(AlpsStats)]),
     "bz_eval_al_gradient": (C.c_int, [_vp, _vp, _vp, _P(C.c_double)]),
     "bz_eval_prox": (C.c_int, [_vp, _vp, C.c_double, _vp, _P(C.c_double)]),
     "bz_eval_lbfgs": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp]),

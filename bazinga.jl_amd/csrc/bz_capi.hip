@@ -179,6 +179,15 @@ int bz_alps_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po
     });
 }
 
+int bz_als_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po, const void* x0,
+                 const void* y0, void* x, void* y, void* s, void* mu, bz_alps_stats* st) {
+    return guard([&] {
+        need(p, "problem"); need(ao, "alps opts"); need(po, "panoc opts");
+        need(x0, "x0"); need(y0, "y0"); need(x, "x"); need(y, "y"); need(s, "s"); need(mu, "mu");
+        p->s->als(*ao, *po, x0, y0, x, y, s, mu, st);
+    });
+}
+
 int bz_eval_al_gradient(bz_problem* p, const void* x, void* dlx, double* vals3) {
     return guard([&] { need(p, "problem"); need(x, "x"); need(vals3, "vals3"); p->s->eval_al_gradient(x, dlx, vals3); });
 }

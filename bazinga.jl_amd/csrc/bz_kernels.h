@@ -1152,6 +1152,111 @@ k_fbstep(const T* __restrict__ x, const T* __restrict__ g, T gamma, ElemParams<T
 }
 
 // ---------------------------------------------------------------------------
+// ALS (slack-variable form, src/algorithms/als.jl, src/utilities/auglagfunslack.jl): the inner
+// solver works on xs = [x; s] of length nx + ny.  c = Identity (ny == nx), element-wise f.
+// ---------------------------------------------------------------------------
+// gradient!(dFxs, F::AugLagFunSlack, xs)  (auglagfunslack.jl:78-97)
+//   w = (cx + muy) - s ; Fxs = 0.5 sum w^2/mu + fx - musqy ; yupd = y + (cx - s)/mu
+//   dFxs = [dfx + yupd ; -yupd]          slots: +0 sum f terms, +1 sum w^2/mu
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_algrad_slack_elem(const T* __restrict__ xs, ElemParams<T> P, const T* __restrict__ yv,
+                    T* __restrict__ grad, int64_t nx, double* __restrict__ parts, int slot0) {
+    double acc[2] = {0.0, 0.0};
+    BZ_FOR_EACH_CHUNK(T, nx) {
+        BZ_CHUNK_VARS(T, nx)
+        Pack<T> px = ld(xs, i0, cnt), ps = ld(xs + nx, i0, cnt);
+        Pack<T> pq = splat(T(0)), pb = splat(T(0));
+        if (P.f_kind == BZ_F_DIAG_QUADRATIC) { pq = ld(P.q, i0, cnt); pb = ld(P.b, i0, cnt); }
+        Pack<T> pmu = ld(P.mu, i0, cnt), pmuy = ld(P.muy, i0, cnt), py = ld(yv, i0, cnt);
+        Pack<T> gx, gs;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            const T x = px.v[e], sv = ps.v[e];
+            T dfx = T(0), fterm = T(0);
+            if (P.f_kind == BZ_F_DIAG_QUADRATIC) {
+                T qx = pq.v[e] * x;
+                dfx = qx - pb.v[e];
+                fterm = x * (T(0.5) * qx - pb.v[e]);
+            }
+            const T cx = x;
+            T w = cx + pmuy.v[e];
+            w = w - sv;
+            const T pterm = (w * w) / pmu.v[e];
+            const T r = cx - sv;
+            const T yupd = py.v[e] + r / pmu.v[e];
+            gx.v[e] = dfx + yupd;
+            gs.v[e] = -yupd;
+            if (e < cnt) { acc[0] += (double)fterm; acc[1] += (double)pterm; }
+        }
+        if (grad) { st(grad, i0, cnt, gx); st(grad + nx, i0, cnt, gs); }
+    }
+    block_reduce_store<2>(acc, 0u, parts, slot0);
+}
+
+// prox!(z, G::NonsmoothCostFunSlack, xs, gamma)  (auglagfunslack.jl:136-154) after the forward step:
+//   z = [prox_g(x - gamma g_x) ; proj_D(s - gamma g_s)] ; res = xs - z
+//   slots: +0 sum g terms (x part), +1 <g, res>, +2 ||res||^2 (both parts)
+template <class T, bool LP = false>
+__global__ void __launch_bounds__(BLOCK)
+k_fbstep_slack(const T* __restrict__ xs, const T* __restrict__ g, T gamma, ElemParams<T> P,
+               T* __restrict__ z, T* __restrict__ res, int64_t nx, double* __restrict__ parts,
+               int slot0) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    const T gl = gamma * P.g_lambda;
+    BZ_FOR_EACH_CHUNK(T, nx) {
+        BZ_CHUNK_VARS(T, nx)
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, false, false, true);
+        Pack<T> dlo = P.D_lo_vec ? ld(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
+        Pack<T> dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
+        Pack<T> px = ld(xs, i0, cnt), ps = ld(xs + nx, i0, cnt);
+        Pack<T> pgx = g ? ld(g, i0, cnt) : splat(T(0)), pgs = g ? ld(g + nx, i0, cnt) : splat(T(0));
+        Pack<T> zx, zs, rx, rs;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T yx = px.v[e], ys = ps.v[e];
+            if (g) { T t = gamma * pgx.v[e]; yx = px.v[e] - t; T u = gamma * pgs.v[e]; ys = ps.v[e] - u; }
+            T gterm;
+            const T a = prox_elem<T, LP>(P.g_kind, yx, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm, P.g_p);
+            const T b = proj_D(P.D_kind, ys, dlo.v[e], dhi.v[e]);
+            const T r1 = px.v[e] - a, r2 = ps.v[e] - b;
+            zx.v[e] = a; zs.v[e] = b; rx.v[e] = r1; rs.v[e] = r2;
+            if (e < cnt) {
+                acc[0] += (double)gterm;
+                acc[1] += (double)(pgx.v[e] * r1);
+                acc[1] += (double)(pgs.v[e] * r2);
+                acc[2] += (double)(r1 * r1);
+                acc[2] += (double)(r2 * r2);
+            }
+        }
+        st(z, i0, cnt, zx); st(z + nx, i0, cnt, zs);
+        if (res) { st(res, i0, cnt, rx); st(res + nx, i0, cnt, rs); }
+    }
+    block_reduce_store<3>(acc, 0u, parts, slot0);
+}
+
+// ALS dual update (als.jl:82-87), c = Identity: y += (cx - s)/mu ; slot +0 max |cx - s|
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_dual_update_slack(const T* __restrict__ xs, const T* __restrict__ mu, T* __restrict__ y,
+                    int64_t nx, double* __restrict__ parts, int slot0) {
+    double acc[1] = {0.0};
+    BZ_FOR_EACH_CHUNK(T, nx) {
+        BZ_CHUNK_VARS(T, nx)
+        Pack<T> px = ld(xs, i0, cnt), ps = ld(xs + nx, i0, cnt), pm = ld(mu, i0, cnt), py = ld((const T*)y, i0, cnt);
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            const T r = px.v[e] - ps.v[e];
+            py.v[e] = py.v[e] + r / pm.v[e];
+            if (e < cnt) acc[0] = nanmax(acc[0], (double)(r < T(0) ? -r : r));
+        }
+        st(y, i0, cnt, py);
+    }
+    block_reduce_store<1>(acc, 1u, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
 // K5+K7: L-BFGS pair + stopping norm
 //   s = x - x_prev ; y = res - res_prev ; slots: +0 <s,y>, +1 <y,y>,
 //   +2 max |res/gamma - gx + gz|

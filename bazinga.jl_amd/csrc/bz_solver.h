@@ -113,6 +113,8 @@ struct SolverBase {
     virtual void solve(const bz_panoc_opts& o, const void* x0, void* x_out, bz_panoc_stats* st) = 0;
     virtual void alps(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0,
                       const void* y0, void* x, void* y, void* s, void* mu, bz_alps_stats* st) = 0;
+    virtual void als(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0,
+                     const void* y0, void* x, void* y, void* s, void* mu, bz_alps_stats* st) = 0;
     virtual void eval_al_gradient(const void* x, void* dlx, double* vals3) = 0;
     virtual void eval_prox(const void* x, double gamma, void* z, double* gz) = 0;
     virtual void eval_lbfgs(int m, const void* S, const void* Y, const void* v, void* d) = 0;

@@ -96,10 +96,19 @@ enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 
 
 template <class T> class Solver final : public SolverBase {
    public:
-    Solver(Ctx* c, const bz_problem_desc& d) : ctx(c), desc(d), n(d.n), ny(d.ny) {
+    Solver(Ctx* c, const bz_problem_desc& d) : ctx(c), desc(d), n(d.n), ny(d.ny), nx(d.n), slack(d.slack != 0) {
         if (n <= 0 || ny < 0) throw Error(BZ_ERR_ARG, "n must be positive");
         if (d.c_kind == BZ_C_IDENTITY && ny != n)
             throw Error(BZ_ERR_ARG, "c = Identity requires ny == n");
+        if (slack) {
+            // ALS: the inner solver works on xs = [x; s]; from here on `n` is the length of that vector
+            if (d.c_kind != BZ_C_IDENTITY || (d.f_kind != BZ_F_ZERO && d.f_kind != BZ_F_DIAG_QUADRATIC))
+                throw Error(BZ_ERR_UNSUPPORTED, "slack (ALS) form: c = Identity and element-wise f only");
+            if (nx % PackN<T>::N != 0)
+                throw Error(BZ_ERR_ARG, "slack (ALS) form: n must be a multiple of 16 bytes");
+            if (ctx->nranks > 1) throw Error(BZ_ERR_UNSUPPORTED, "slack (ALS) form is not sharded");
+            n = nx + ny;
+        }
         if (d.c_kind != BZ_C_IDENTITY && d.c_kind != BZ_C_DENSE_AFFINE)
             throw Error(BZ_ERR_UNSUPPORTED, "constraint kind not lowered to the device");
         if (d.c_kind == BZ_C_DENSE_AFFINE) {
@@ -153,6 +162,10 @@ template <class T> class Solver final : public SolverBase {
         const int64_t nychunks = (ny + PackN<T>::N - 1) / PackN<T>::N;
         grid_y = (int)std::min<int64_t>(grid, std::max<int64_t>(1, (nychunks + BLOCK - 1) / BLOCK));
         if (d.c_kind == BZ_C_IDENTITY) grid_y = grid;
+        if (slack) {
+            const int64_t c2 = (nx / PackN<T>::N + BLOCK - 1) / BLOCK;
+            grid_y = (int)std::min<int64_t>(PSTRIDE, std::max<int64_t>(1, c2));
+        }
         npad = ((n + PackN<T>::N - 1) / PackN<T>::N) * PackN<T>::N;
         if (dense_f) {
             frows = d.f_rows;
@@ -182,7 +195,7 @@ template <class T> class Solver final : public SolverBase {
         P.f_kind = d.f_kind; P.g_kind = d.g_kind; P.D_kind = d.D_kind;
         if (d.f_kind == BZ_F_DIAG_QUADRATIC) {
             if (!d.f_q || !d.f_b) throw Error(BZ_ERR_ARG, "DiagQuadratic needs q and b");
-            upload(q_, d.f_q, n); upload(b_, d.f_b, n);
+            upload(q_, d.f_q, nx); upload(b_, d.f_b, nx);
             P.q = q_.p; P.b = b_.p;
         }
         if (dense_f) P.b = fb_.p;                          // Quadratic: q, read by the element-wise kernels
@@ -201,12 +214,12 @@ template <class T> class Solver final : public SolverBase {
         }
         if (d.g_kind == BZ_G_NORM_L1_BOX || d.g_kind == BZ_G_NORM_L0_BOX || d.g_kind == BZ_G_NORM_LP_BOX) {
             if (!d.g_u) throw Error(BZ_ERR_ARG, "NormL1Box / NormL0Box / NormLpPowerBox need u");
-            upload(gu_, d.g_u, n); P.g_u = gu_.p;
+            upload(gu_, d.g_u, nx); P.g_u = gu_.p;
         }
         P.g_lo = (T)d.g_lo; P.g_hi = (T)d.g_hi;
         if (d.g_kind == BZ_G_IND_BOX) {
-            if (d.g_lo_vec) { upload(glo_, d.g_lo_vec, n); P.g_lo_vec = glo_.p; }
-            if (d.g_hi_vec) { upload(ghi_, d.g_hi_vec, n); P.g_hi_vec = ghi_.p; }
+            if (d.g_lo_vec) { upload(glo_, d.g_lo_vec, nx); P.g_lo_vec = glo_.p; }
+            if (d.g_hi_vec) { upload(ghi_, d.g_hi_vec, nx); P.g_hi_vec = ghi_.p; }
         }
         P.D_lo = (T)d.D_lo; P.D_hi = (T)d.D_hi;
         if (d.D_kind == BZ_D_BOX) {
@@ -365,6 +378,7 @@ template <class T> class Solver final : public SolverBase {
     // ------------------------------------------------------- alps (alps.jl:7-117)
     void alps(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0, const void* y0,
               void* xo, void* yo, void* so, void* muo, bz_alps_stats* st) override {
+        if (slack) throw Error(BZ_ERR_STATE, "bz_alps_solve on a slack (ALS) problem: use bz_als_solve");
         auto t0 = std::chrono::steady_clock::now();
         const T epsT = std::numeric_limits<T>::epsilon();
         T* x = X_[0].p;
@@ -446,11 +460,84 @@ template <class T> class Solver final : public SolverBase {
         }
     }
 
+    // ------------------------------------------------------- als (als.jl:7-120)
+    void als(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0, const void* y0,
+             void* xo, void* yo, void* so, void* muo, bz_alps_stats* st) override {
+        if (!slack) throw Error(BZ_ERR_STATE, "bz_als_solve needs a problem created with desc.slack = 1");
+        auto t0 = std::chrono::steady_clock::now();
+        const T epsT = std::numeric_limits<T>::epsilon();
+        T* xs = X_[0].p;                                   // [x; s]
+        copy_in(TMP_.p, x0, nx);
+        // prox!(x, gFun, x0, eps(T)) ; objx = f(x) + gFun.gz              als.jl:41-42
+        if (lp_g) launch(C_FB, k_fbstep<T, true>, grid_y, (const T*)TMP_.p, (const T*)nullptr, epsT, P, xs, (T*)nullptr, nx, parts_.p, (int)SL_GSUM);
+        else launch(C_FB, k_fbstep<T, false>, grid_y, (const T*)TMP_.p, (const T*)nullptr, epsT, P, xs, (T*)nullptr, nx, parts_.p, (int)SL_GSUM);
+        for (int k = 0; k < 3; ++k) slot_n[SL_GSUM + k] = grid_y;
+        fvalue(xs, SL_AUX);
+        auto v0 = collect({SL_GSUM, SL_AUX}, 0u);
+        T objx = f_value(v0[1]) + g_value(v0[0]);
+        // eval!(cx,c,x); proj!(s,D,cx); default_penalty_parameter!          als.jl:43-45   (s lands in xs[nx:])
+        launch(C_MISC, k_penalty_init<T>, grid_y, (const T*)xs, P, std::max(1.0, (double)objx), xs + nx, mu_.p, ny);
+        copy_in(ymul_.p, y0, ny);
+        double norm_res_prim = 0, norm_res_prim_old = 0;
+        bool have_old = false, have_res = false;
+        int64_t tot_it = 0, tot_inner = 0;
+        double inner_tol = ao.inner_tol;
+        bool solved = false, tired = tot_it >= ao.maxit, broken = std::isnan((double)objx);
+        if (ao.verbose) std::printf("[ Info: initial inner tolerance %g\n", inner_tol);
+        bool can_stop = solved || tired || broken;
+        bz_panoc_opts po2 = po;
+        while (!can_stop) {
+            ++tot_it;
+            launch(C_MISC, k_clamp_scale<T>, grid_y, ymul_.p, -1e20, 1e20, T(1), 1, ny);     // dual_safeguard
+            po2.tol = inner_tol; po2.verbose = ao.verbose;
+            aug_lag_update();                                        // AugLagUpdate!(fSlack, mu, y)
+            begin_dev(po2, xs);                                      // sub_solver(f=fSlack, g=gSlack, x0=xSlack)
+            run_to_completion();
+            const int64_t sub_it = k_;
+            xs = Z_[zc].p;                                           // xSlack .= sub_sol
+            objx = fraw_last + g_z;                                  // f(x) + gSlack.gz       als.jl:79
+            tot_inner += sub_it;
+            const bool sub_solved = sub_it < ao.subsolver_maxit;
+            // y += (cx - s)/mu ; ||cx - s||_inf                      als.jl:82-87
+            launch(C_MISC, k_dual_update_slack<T>, grid_y, (const T*)xs, (const T*)mu_.p, ymul_.p, nx, parts_.p,
+                   (int)SL_OUTER);
+            slot_n[SL_OUTER] = grid_y;
+            gather(SL_OUTER, 1, 1u);
+            auto r = collect({SL_OUTER}, 1u);
+            norm_res_prim_old = norm_res_prim; have_old = have_res;
+            norm_res_prim = r[0]; have_res = true;
+            solved = (inner_tol <= ao.tol_dual && sub_solved) && (norm_res_prim <= ao.tol_prim);
+            tired = tot_it >= ao.maxit;
+            broken = std::isnan((double)objx);
+            can_stop = solved || tired || broken;
+            if (!can_stop) {
+                if (have_old && norm_res_prim > std::max(ao.theta_penalty * norm_res_prim_old, ao.tol_prim))
+                    launch(C_MISC, k_clamp_scale<T>, grid_y, mu_.p, 0.0, 0.0, (T)ao.kappa_penalty, 0, ny);
+                inner_tol = std::max(ao.kappa_tol * inner_tol, ao.tol_dual);
+                BZ_HIP(hipMemcpyAsync(X_[0].p, xs, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+                xs = X_[0].p;
+            }
+        }
+        copy_out(xo, xs, nx);
+        copy_out(so, xs + nx, ny);
+        copy_out(yo, ymul_.p, ny);
+        copy_out(muo, mu_.p, ny);
+        if (st) {
+            st->tot_it = tot_it; st->tot_inner_it = tot_inner;
+            st->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            st->status = solved ? 0 : (tired ? 1 : (broken ? 2 : 3));
+            st->inner_tol = inner_tol; st->norm_res_prim = norm_res_prim;
+            st->objective = (double)objx;
+        }
+    }
+
    private:
     // ------------------------------------------------------------ plumbing
     Ctx* ctx;
     bz_problem_desc desc;
     int64_t n, ny;
+    int64_t nx;                              // length of x (== n unless slack: then n = nx + ny)
+    bool slack;
     int grid = 1, grid_y = 1;
     ElemParams<T> P;
     DBuf<T> q_, b_, gu_, glo_, ghi_, dlo_, dhi_, mu_, muy_, ymul_, sproj_;
@@ -624,6 +711,13 @@ template <class T> class Solver final : public SolverBase {
     // forward-backward step kernel; the Newton/pow prox kinds use their own instantiation so the
     // common kinds keep their register budget
     void fbstep(const T* x, const T* g, T gam, T* z, T* res, int slot0) {
+        if (slack) {
+            for (int k = 0; k < 3; ++k) slot_n[slot0 + k] = grid_y;
+            if (lp_g) launch(C_FB, k_fbstep_slack<T, true>, grid_y, x, g, gam, P, z, res, nx, parts_.p, slot0);
+            else launch(C_FB, k_fbstep_slack<T, false>, grid_y, x, g, gam, P, z, res, nx, parts_.p, slot0);
+            return;
+        }
+        for (int k = 0; k < 3; ++k) slot_n[slot0 + k] = grid;
         if (lp_g) launch(C_FB, k_fbstep<T, true>, grid, x, g, gam, P, z, res, n, parts_.p, slot0);
         else launch(C_FB, k_fbstep<T, false>, grid, x, g, gam, P, z, res, n, parts_.p, slot0);
     }
@@ -702,6 +796,12 @@ template <class T> class Solver final : public SolverBase {
             return;
         }
         slot_n[slot0] = slot_n[slot0 + 1] = grid;
+        if (slack) {
+            slot_n[slot0] = slot_n[slot0 + 1] = grid_y;
+            launch(C_ALGRAD, k_algrad_slack_elem<T>, grid_y, x, P, (const T*)ymul_.p, grad, nx, parts_.p, slot0);
+            gather(slot0, 2, 0u);
+            return;
+        }
         if (dense_f) {
             dense_f_eval(x, slot0, true);
             if (desc.f_kind == BZ_F_LEAST_SQUARES)
@@ -719,6 +819,12 @@ template <class T> class Solver final : public SolverBase {
     // f(x) alone (alps.jl:39): partial sums -> slot0
     void fvalue(const T* x, int slot0) {
         slot_n[slot0] = grid;
+        if (slack) {      // f on the x part only
+            slot_n[slot0] = grid_y;
+            launch(C_MISC, k_fvalue_elem<T>, grid_y, x, P, nx, parts_.p, slot0, (const T*)nullptr);
+            gather(slot0, 1, 0u);
+            return;
+        }
         if (dense_f) {
             dense_f_eval(x, slot0, false);
             if (desc.f_kind == BZ_F_QUADRATIC)
@@ -880,7 +986,7 @@ template <class T> class Solver final : public SolverBase {
         alloc_history();
         lbfgs_reset_all();
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
-        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g &&
+        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread

@@ -92,10 +92,11 @@ def shard_bounds(n: int, rank: int, nranks: int, align: int = 256):
 class Problem:
     """bz_problem: the lowered (f, g, c, D) with its device-resident data and solver state."""
 
-    def __init__(self, f, g, c, D, n, ny, dtype, ctx: Context | None = None):
+    def __init__(self, f, g, c, D, n, ny, dtype, ctx: Context | None = None, slack: bool = False):
         self.ctx = ctx or default_context()
-        self.n, self.ny, self.dtype = int(n), int(ny), np.dtype(dtype)
-        desc, keep = lower(f, g, c, D, self.n, self.ny, self.dtype)
+        self.nx, self.ny, self.dtype, self.slack = int(n), int(ny), np.dtype(dtype), bool(slack)
+        self.n = self.nx + self.ny if slack else self.nx       # length of the inner decision vector
+        desc, keep = lower(f, g, c, D, self.nx, self.ny, self.dtype, slack)
         h = C.c_void_p()
         L.check(L.load().bz_problem_create(self.ctx._h, C.byref(desc), C.byref(h)))
         del keep
@@ -152,11 +153,12 @@ class Problem:
         return out
 
     def alps_solve(self, aopts: L.AlpsOpts, popts: L.PanocOpts, x0, y0):
-        x0, y0 = self._in(x0, self.n), self._in(y0, self.ny)
-        x = np.empty(self.n, self.dtype)
+        x0, y0 = self._in(x0, self.nx), self._in(y0, self.ny)
+        x = np.empty(self.nx, self.dtype)
         y, s, mu = (np.empty(self.ny, self.dtype) for _ in range(3))
         st = L.AlpsStats()
-        L.check(L.load().bz_alps_solve(self._h, C.byref(aopts), C.byref(popts), x0.ctypes.data, y0.ctypes.data,
+        fn = L.load().bz_als_solve if self.slack else L.load().bz_alps_solve
+        L.check(fn(self._h, C.byref(aopts), C.byref(popts), x0.ctypes.data, y0.ctypes.data,
                                        x.ctypes.data, y.ctypes.data, s.ctypes.data, mu.ctypes.data, C.byref(st)))
         return x, y, s, mu, st
 

@@ -210,8 +210,9 @@ def _vec(a, dtype, n, name):
     return v
 
 
-def lower(f, g, c, D, n, ny, dtype):
-    """(f, g, c, D) -> (ProblemDesc, keepalive list).  Raises UnsupportedOracle."""
+def lower(f, g, c, D, n, ny, dtype, slack=False):
+    """(f, g, c, D) -> (ProblemDesc, keepalive list).  Raises UnsupportedOracle.
+    slack=True: the ALS form on xs = [x; s] (src/utilities/auglagfunslack.jl)."""
     dtype = np.dtype(dtype)
     if dtype == np.float64:
         code = L.BZ_F64
@@ -222,6 +223,7 @@ def lower(f, g, c, D, n, ny, dtype):
     d = L.ProblemDesc()
     keep = []
     d.dtype, d.n, d.ny = code, n, ny
+    d.slack = 1 if slack else 0
 
     def ptr(a):
         keep.append(a)

@@ -81,7 +81,40 @@ class AugLagFun:
         return self._problem
 
 
-def AugLagUpdate(al: AugLagFun, mu, y):
+class AugLagFunSlack:
+    """src/utilities/auglagfunslack.jl:15-54: smooth part of the slack-form AL on xs = [x; s]."""
+
+    def __init__(self, f, c, mu, y, x):
+        if np.any(mu <= 0):
+            raise ValueError("parameters `mu` must be positive")
+        self.f, self.c = f, c
+        self.nx, self.ny = x.shape[0], y.shape[0]
+        self.mu, self.y = mu, y
+        self.muy = mu * y
+        self.musqy = x.dtype.type(0.5) * np.sum(self.muy * y)
+        self.fx = x.dtype.type(0)
+        self.dtype = x.dtype
+        self._problem = None
+        self._problem_key = None
+
+    def problem(self, g, D, ctx=None) -> Problem:
+        key = (id(g), id(D), id(ctx))
+        if self._problem is None or self._problem_key != key:
+            self._problem = Problem(self.f, g, self.c, D, self.nx, self.ny, self.dtype, ctx, slack=True)
+            self._problem_key = key
+        return self._problem
+
+
+class NonsmoothCostFunSlack:
+    """src/utilities/auglagfunslack.jl:118-154: prox of [x; s] = [prox_g(x); proj_D(s)]."""
+
+    def __init__(self, g, D, nx, ny):
+        self.g, self.D, self.nx, self.ny = g, D, nx, ny
+        self.gamma = 0.0
+        self.gz = 0.0
+
+
+def AugLagUpdate(al, mu, y):
     """src/utilities/auglagfun.jl:91-101"""
     if np.any(mu <= 0):
         raise ValueError("parameters `mu` must be positive")
@@ -122,9 +155,13 @@ class PANOCplus:
         return o
 
     def __call__(self, *, f, g, x0):
-        if not isinstance(f, AugLagFun) or not isinstance(g, NonsmoothCostFun):
-            raise UnsupportedOracle("the device subsolver takes f=AugLagFun(...), g=NonsmoothCostFun(...)")
-        prob = f.problem(g.g, self.ctx)
+        if isinstance(f, AugLagFunSlack) and isinstance(g, NonsmoothCostFunSlack):
+            prob = f.problem(g.g, g.D, self.ctx)            # ALS seam, als.jl:68-72
+        elif isinstance(f, AugLagFun) and isinstance(g, NonsmoothCostFun):
+            prob = f.problem(g.g, self.ctx)
+        else:
+            raise UnsupportedOracle("the device subsolver takes f=AugLagFun(...), g=NonsmoothCostFun(...) "
+                                    "or their Slack forms")
         prob.set_multipliers(f.mu, f.y)
         z, st = prob.panoc_solve(self.c_opts(), x0)
         f.fx = x0.dtype.type(st.f_z)            # side channels read by alps.jl:68
@@ -139,10 +176,17 @@ default_subsolver = PANOCplus
 _STATUS = ("first_order", "max_iter", "exception", "unknown")
 
 
+def als(f, g, c, D, x0, y0, **kw):
+    """Bazinga.als (src/algorithms/als.jl:7-120): the slack-variable sibling of `alps` — same keywords,
+    same 10-tuple; the inner solver works on xs = [x; s] with the block prox [prox_g; proj_D]
+    (src/utilities/auglagfunslack.jl)."""
+    return alps(f, g, c, D, x0, y0, _slack=True, **kw)
+
+
 def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol=None, maxit=100,
          theta_penalty=0.8, kappa_penalty=0.5, kappa_tol=0.1, verbose=False,
          dual_safeguard=default_dual_safeguard, subsolver=default_subsolver,
-         subsolver_maxit=1_000_000_000, resident=None, ctx=None):
+         subsolver_maxit=1_000_000_000, resident=None, ctx=None, _slack=False):
     """Bazinga.alps (src/algorithms/alps.jl:7-117): same keywords and defaults, same 10-tuple
     ``(x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu)``
     (status is the Symbol's name as a string).  x0 / y0 are never mutated.
@@ -166,7 +210,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         sub = subsolver(tol=inner_tol, verbose=verbose)
         if not isinstance(sub, PANOCplus):
             raise UnsupportedOracle("resident=True needs a PANOCplus subsolver factory")
-        prob = Problem(f, g, c, D, x0.shape[0], y0.shape[0], x0.dtype, ctx or sub.ctx)
+        prob = Problem(f, g, c, D, x0.shape[0], y0.shape[0], x0.dtype, ctx or sub.ctx, slack=_slack)
         ao = L.AlpsOpts()
         L.load().bz_alps_default_opts(C.byref(ao), L.BZ_F64 if x0.dtype == np.float64 else L.BZ_F32)
         ao.tol_prim, ao.tol_dual, ao.inner_tol = float(tol_prim), float(tol_dual), float(inner_tol)
@@ -200,6 +244,10 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     probe.close()
     norm_res_prim = None
     norm_res_prim_old = None
+    if _slack:
+        return _als_host_loop(f, g, c, D, x, y, cx, s, mu, gFun, objx, tol_prim, tol_dual, inner_tol, maxit,
+                              theta_penalty, kappa_penalty, kappa_tol, verbose, dual_safeguard, subsolver,
+                              subsolver_maxit, start_time)
     alFun = AugLagFun(f, c, D, mu, y, x)                        # :46
     tot_it = 0
     tot_inner_it = 0
@@ -237,6 +285,57 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
             elif norm_res_prim > max(theta_penalty * norm_res_prim_old, tol_prim):
                 mu *= T(kappa_penalty)                          # :97
             inner_tol = max(kappa_tol * inner_tol, tol_dual)    # :100
+    elapsed_time = time.time() - start_time
+    status = "first_order" if solved else ("max_iter" if tired else ("exception" if broken else "unknown"))
+    return x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu
+
+
+def _als_host_loop(f, g, c, D, x, y, cx, s, mu, gFun, objx, tol_prim, tol_dual, inner_tol, maxit, theta_penalty,
+                   kappa_penalty, kappa_tol, verbose, dual_safeguard, subsolver, subsolver_maxit, start_time):
+    """als.jl:46-118 on the host, device at the subsolver seam (line numbers: src/algorithms/als.jl)."""
+    T = x.dtype.type
+    nx, ny = x.shape[0], y.shape[0]
+    xSlack = np.zeros(nx + ny, dtype=x.dtype)                   # :35
+    norm_res_prim = None
+    norm_res_prim_old = None
+    fSlack = AugLagFunSlack(f, c, mu, y, x)                     # :49
+    gSlack = NonsmoothCostFunSlack(g, D, nx, ny)                # :50
+    tot_it = 0
+    tot_inner_it = 0
+    solved = False
+    tired = tot_it >= maxit
+    broken = bool(np.isnan(objx))
+    can_stop = solved or tired or broken
+    while not can_stop:
+        tot_it += 1
+        dual_safeguard(y, cx)                                   # :66
+        sub_solver = subsolver(tol=inner_tol, verbose=verbose)  # :68
+        AugLagUpdate(fSlack, mu, y)                             # :69
+        xSlack[:nx] = x                                         # :70-71
+        xSlack[nx:] = s
+        sub_sol, sub_it = sub_solver(f=fSlack, g=gSlack, x0=xSlack)   # :72
+        if sub_sol.shape[0] != nx + ny:
+            raise ValueError("wrong dimension of sub_sol")
+        xSlack[...] = sub_sol
+        x[...] = xSlack[:nx]
+        s[...] = xSlack[nx:]
+        objx = fSlack.fx + gSlack.gz                            # :79  f(x) at the returned point
+        tot_inner_it += sub_it
+        sub_solved = sub_it < subsolver_maxit
+        cx[...] = _eval_c_host(c, x)                            # :82
+        y[...] = y + (cx - s) / mu                              # :84
+        norm_res_prim_old = norm_res_prim
+        norm_res_prim = np.max(np.abs(cx - s))                  # :87
+        solved = (inner_tol <= tol_dual and sub_solved) and norm_res_prim <= tol_prim
+        tired = tot_it >= maxit
+        broken = bool(np.isnan(objx))
+        can_stop = solved or tired or broken
+        if not can_stop:
+            if norm_res_prim_old is None:
+                pass
+            elif norm_res_prim > max(theta_penalty * norm_res_prim_old, tol_prim):
+                mu *= T(kappa_penalty)                          # :100
+            inner_tol = max(kappa_tol * inner_tol, tol_dual)    # :103
     elapsed_time = time.time() - start_time
     status = "first_order" if solved else ("max_iter" if tired else ("exception" if broken else "unknown"))
     return x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu

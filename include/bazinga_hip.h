@@ -104,7 +104,8 @@ int  bz_device_info(bz_ctx* ctx, char* name256, int32_t* cus, int64_t* mem_bytes
 typedef struct {
     int32_t dtype;                 /* BZ_F64 | BZ_F32                                 */
     int32_t f_kind, g_kind, c_kind, D_kind;
-    int32_t data_on_device;        /* informational: pointers below may be host or device */
+    int32_t slack;                 /* 0: ALPS subproblem on x (auglagfun.jl); 1: ALS subproblem on
+                                      xs = [x; s] of length n + ny (auglagfunslack.jl)      */
     int64_t n;                     /* length of x (local shard)                       */
     int64_t ny;                    /* length of y / c(x) (local shard)                */
     /* f */
@@ -225,6 +226,12 @@ typedef struct {
 int bz_alps_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po,
                   const void* x0, const void* y0,
                   void* x, void* y, void* s, void* mu, bz_alps_stats* stats);
+
+/* Bazinga.als (src/algorithms/als.jl:7-120), the slack-variable sibling: same arguments and outputs;
+ * the problem must have been created with desc.slack = 1.                                            */
+int bz_als_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po,
+                 const void* x0, const void* y0,
+                 void* x, void* y, void* s, void* mu, bz_alps_stats* stats);
 
 /* ---- single oracle evaluations on the device (kernel-level parity tests) ---- */
 /* gradient!(dlx, al, x) -> lx   (auglagfun.jl:73-86).  vals = {lx, fx, 0.5*sum t^2/mu} */

@@ -22,7 +22,7 @@ struct CtxOpts
 end
 Base.@kwdef mutable struct ProblemDesc
     dtype::Int32 = 0; f_kind::Int32 = 0; g_kind::Int32 = 0; c_kind::Int32 = 0; D_kind::Int32 = 0
-    data_on_device::Int32 = 0
+    slack::Int32 = 0
     n::Int64 = 0; ny::Int64 = 0
     f_q::Ptr{Cvoid} = C_NULL; f_b::Ptr{Cvoid} = C_NULL; f_grid_nx::Int64 = 0; f_grid_ny::Int64 = 0
     f_A::Ptr{Cvoid} = C_NULL; f_rows::Int64 = 0

@@ -1003,3 +1003,164 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     else:
         status = "unknown"
     return x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu
+
+
+# ---------------------------------------------------------------------------
+#  ALS: the slack-variable sibling of ALPS
+#    src/utilities/auglagfunslack.jl:15-154 ; src/algorithms/als.jl:7-120
+# ---------------------------------------------------------------------------
+class AugLagFunSlack:
+    """auglagfunslack.jl:15-114.  al_f(x,s) = f(x) + 1/(2mu)||c(x) + mu y - s||^2 - mu/2 ||y||^2 on xs = [x; s]."""
+
+    def __init__(self, f, c, mu, y, x):
+        if REDUCER.any(mu <= 0):                               # :35-37
+            raise ValueError("parameters `mu` must be positive")
+        T = x.dtype.type
+        self.f, self.c = f, c
+        self.nx, self.ny = x.shape[0], y.shape[0]
+        self.mu, self.y = mu, y
+        self.muy = mu * y
+        self.musqy = T(0.5) * _sum(self.muy * y)
+        self.cx = np.empty_like(y)
+        self.yupd = np.empty_like(y)
+        self.dfx = np.empty_like(x)
+        self.jtv = np.empty_like(x)
+        self.n_grad = 0
+
+    def __call__(self, xs):                                    # :59-73
+        T = xs.dtype.type
+        if xs.shape[0] != self.nx + self.ny:
+            raise ValueError("wrong length of passed argument xs")
+        x, s = xs[:self.nx].copy(), xs[self.nx:].copy()
+        fx = self.f(x)
+        self.c.eval(self.cx, x)
+        self.yupd[...] = self.cx + self.muy - s
+        Fxs = T(0.5) * _sum(self.yupd ** 2 / self.mu)
+        Fxs += fx
+        Fxs -= self.musqy
+        self.yupd[...] = self.y + (self.cx - s) / self.mu
+        return Fxs
+
+    def gradient(self, dFxs, xs):                              # :78-97
+        T = xs.dtype.type
+        if xs.shape[0] != self.nx + self.ny or dFxs.shape[0] != self.nx + self.ny:
+            raise ValueError("wrong length of passed argument")
+        self.n_grad += 1
+        x, s = xs[:self.nx].copy(), xs[self.nx:].copy()
+        fx = self.f.gradient(self.dfx, x)
+        self.c.eval(self.cx, x)
+        Fxs = T(0.5) * _sum((self.cx + self.muy - s) ** 2 / self.mu)
+        Fxs += fx
+        Fxs -= self.musqy
+        self.yupd[...] = self.y + (self.cx - s) / self.mu
+        self.c.jtprod(self.jtv, x, self.yupd)
+        dFxs[:self.nx] = self.dfx + self.jtv
+        dFxs[self.nx:] = -self.yupd
+        return Fxs
+
+
+def AugLagUpdateSlack(F: AugLagFunSlack, mu, y):              # :102-114
+    if REDUCER.any(mu <= 0):
+        raise ValueError("parameters `mu` must be positive")
+    if y.shape[0] != F.ny:
+        raise ValueError("wrong length of passed argument y")
+    T = y.dtype.type
+    F.mu[...] = mu
+    F.y[...] = y
+    F.muy[...] = F.mu * F.y
+    F.musqy = T(0.5) * _sum(F.muy * F.y)
+    return None
+
+
+class NonsmoothCostFunSlack:
+    """auglagfunslack.jl:118-154: prox of [x; s] = [prox_g(x); proj_D(s)]."""
+
+    def __init__(self, g, D, nx, ny):
+        self.g, self.D, self.nx, self.ny = g, D, nx, ny
+        self.gamma = 0.0
+        self.gz = 0.0
+
+    def prox(self, z, xs, gamma):
+        if xs.shape[0] != self.nx + self.ny or z.shape[0] != self.nx + self.ny:
+            raise ValueError("wrong length of passed argument")
+        self.gamma = gamma
+        x, s = xs[:self.nx].copy(), xs[self.nx:].copy()
+        zx = np.empty_like(x)
+        gz = self.g.prox(zx, x, gamma)
+        z[:self.nx] = zx
+        self.gz = gz
+        zs = np.empty_like(s)
+        self.D.proj(zs, s)
+        z[self.nx:] = zs
+        return gz
+
+
+def als(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol=None, maxit=100,
+        theta_penalty=0.8, kappa_penalty=0.5, kappa_tol=0.1, verbose=False,
+        dual_safeguard=default_dual_safeguard, subsolver=default_subsolver,
+        subsolver_maxit=1_000_000_000):
+    """als.jl:7-120.  Same 10-tuple as alps."""
+    start_time = time.time()
+    T = x0.dtype.type
+    nx, ny = x0.shape[0], y0.shape[0]
+    if tol is None:
+        tol = T(1e-6)
+    tol_prim = tol if tol_prim is None else tol_prim
+    tol_dual = tol if tol_dual is None else tol_dual
+    inner_tol = float(np.cbrt(tol_dual)) if inner_tol is None else inner_tol
+    x = np.empty_like(x0)
+    s = np.empty_like(y0)
+    xSlack = np.zeros(nx + ny, dtype=x0.dtype)
+    y = np.empty_like(y0)
+    cx = np.empty_like(y0)
+    mu = np.empty_like(y0)
+    gFun = NonsmoothCostFun(g)
+    gFun.prox(x, x0, np.finfo(x0.dtype).eps)                   # :41
+    objx = f(x) + gFun.gz
+    c.eval(cx, x)
+    D.proj(s, cx)
+    default_penalty_parameter(mu, cx, s, objx)
+    y[...] = y0
+    norm_res_prim = None
+    norm_res_prim_old = None
+    fSlack = AugLagFunSlack(f, c, mu, y, x)                    # :49
+    gSlack = NonsmoothCostFunSlack(g, D, nx, ny)               # :50
+    tot_it = 0
+    tot_inner_it = 0
+    solved = False
+    tired = tot_it >= maxit
+    broken = bool(np.isnan(objx))
+    can_stop = solved or tired or broken
+    while not can_stop:
+        tot_it += 1
+        dual_safeguard(y, cx)                                  # :66
+        sub_solver = subsolver(tol=inner_tol, verbose=verbose)
+        AugLagUpdateSlack(fSlack, mu, y)                       # :69
+        xSlack[:nx] = x
+        xSlack[nx:] = s
+        sub_sol, sub_it = sub_solver(f=fSlack, g=gSlack, x0=xSlack)   # :72
+        if sub_sol.shape[0] != nx + ny:
+            raise ValueError("wrong dimension of sub_sol")
+        xSlack[...] = sub_sol
+        x[...] = xSlack[:nx]
+        s[...] = xSlack[nx:]
+        objx = f(x) + gSlack.gz                                # :79
+        tot_inner_it += sub_it
+        sub_solved = sub_it < subsolver_maxit
+        c.eval(cx, x)
+        y[...] = y + (cx - s) / mu                             # :84
+        norm_res_prim_old = norm_res_prim
+        norm_res_prim = _max(np.abs(cx - s))                   # :87
+        solved = (inner_tol <= tol_dual and sub_solved) and norm_res_prim <= tol_prim
+        tired = tot_it >= maxit
+        broken = bool(np.isnan(objx))
+        can_stop = solved or tired or broken
+        if not can_stop:
+            if norm_res_prim_old is None:
+                pass
+            elif norm_res_prim > max(theta_penalty * norm_res_prim_old, tol_prim):
+                mu *= T(kappa_penalty)
+            inner_tol = max(kappa_tol * inner_tol, tol_dual)
+    elapsed_time = time.time() - start_time
+    status = "first_order" if solved else ("max_iter" if tired else ("exception" if broken else "unknown"))
+    return x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu

@@ -1,0 +1,103 @@
+"""ALS — the slack-variable sibling of ALPS (src/algorithms/als.jl, src/utilities/auglagfunslack.jl;
+SURVEY.md §8(f-3)) — through the device path, against the CPU oracle's restatement of the same files."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import RTOL_ITER, LongDoubleReducer, iter_tol, make_cfg2, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [2, 1000, 70002])
+@pytest.mark.parametrize("D", ["box", "free", "zero"])
+def test_slack_gradient_and_prox_bit_exact(bz, ref, n, D):
+    """gradient!(dFxs, F::AugLagFunSlack, xs) (auglagfunslack.jl:78-97) and
+    prox!(z, G::NonsmoothCostFunSlack, xs, gamma) (:136-154): element-wise bit-exact."""
+    d, dev, orc = make_cfg2(bz, ref, n, D=D)
+    rng = np.random.default_rng(n + 3)
+    xs = rng.standard_normal(2 * n)
+    mu = 10.0 ** rng.uniform(-2, 0, n)
+    y = rng.standard_normal(n)
+    prob = bz.Problem(*dev, n, n, np.float64, slack=True)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(xs)
+    F = ref.AugLagFunSlack(orc[0], orc[2], mu.copy(), y.copy(), xs[:n])
+    g_ref = np.empty(2 * n)
+    Fxs = F.gradient(g_ref, xs)
+    assert np.array_equal(g_dev, g_ref)
+    assert abs(vals[0] - Fxs) <= 1e-13 * max(1.0, abs(Fxs))
+    z_dev, gz_dev = prob.eval_prox(xs, 0.41)
+    G = ref.NonsmoothCostFunSlack(orc[1], orc[3], n, n)
+    z_ref = np.empty(2 * n)
+    gz_ref = G.prox(z_ref, xs, 0.41)
+    assert np.array_equal(z_dev, z_ref)
+    assert abs(gz_dev - gz_ref) <= 1e-13 * max(1.0, abs(gz_ref))
+    prob.close()
+
+
+@pytest.mark.parametrize("n", [1000, 400002])
+def test_slack_panoc_iterates_match_oracle(bz, ref, n):
+    d, dev, orc = make_cfg2(bz, ref, n)
+    rng = np.random.default_rng(8)
+    mu, y = np.full(n, 0.1), rng.standard_normal(n)
+    xs0 = np.concatenate([np.zeros(n), np.clip(rng.standard_normal(n), -1, 1)])
+    prob = bz.Problem(*dev, n, n, np.float64, slack=True)
+    prob.set_multipliers(mu, y)
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), xs0)
+    its, sts = [], []
+    for red in (None, LongDoubleReducer()):
+        ref.set_reducer(red)
+        F = ref.AugLagFunSlack(orc[0], orc[2], mu.copy(), y.copy(), xs0[:n])
+        it = ref.PANOCplusIteration(F, ref.NonsmoothCostFunSlack(orc[1], orc[3], n, n), xs0)
+        its.append(it)
+        sts.append(it.init())
+    ref.set_reducer(None)
+    env = 0.0
+    for k in range(25):
+        env = max(env, rel(sts[1].x, sts[0].x), rel(sts[1].z, sts[0].z))
+        ex, ez = rel(prob.panoc_vector("x"), sts[0].x), rel(prob.panoc_vector("z"), sts[0].z)
+        assert ex <= iter_tol(env) and ez <= iter_tol(env), (k, ex, ez, env)
+        if k < 10:
+            assert ex <= RTOL_ITER and ez <= RTOL_ITER
+        prob.panoc_step()
+        sts[0] = its[0].step(sts[0])
+        ref.set_reducer(LongDoubleReducer())
+        sts[1] = its[1].step(sts[1])
+        ref.set_reducer(None)
+    prob.close()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_als_matches_oracle_and_alps(bz, ref, resident):
+    n = 3000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    a = bz.als(*dev, x0, y0, resident=resident)
+    o = ref.als(*orc, x0, y0)
+    assert a[5] == o[5] == "first_order"
+    assert a[2] == o[2]
+    assert abs(a[3] - o[3]) <= max(3, 0.03 * o[3])
+    assert rel(a[0], o[0]) <= 1e-7
+    assert np.max(np.abs(a[1] - o[1])) <= 1e-6 * max(1.0, np.max(np.abs(o[1])))
+    assert np.max(np.abs(a[8] - o[8])) <= 1e-6                       # slack certificate s
+    b = bz.alps(*dev, x0, y0)                                        # same minimiser as ALPS
+    assert np.max(np.abs(a[0] - b[0])) <= 1e-5
+    assert not np.any(x0)
+
+
+def test_als_rejects_unsupported(bz, ref):
+    n = 64
+    d = bz.synth.obstacle_grid(8, 8)
+    with pytest.raises(bz.BazingaHipError):
+        bz.Problem(bz.Stencil5ptQuadratic(8, 8, d["b"]), bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), n, n,
+                   np.float64, slack=True)
+    d2, dev, orc = make_cfg2(bz, ref, n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    ao, po = bz._lib.AlpsOpts(), bz.PANOCplus().c_opts()
+    prob.slack = True                       # force the ALS entry point onto an ALPS problem
+    import ctypes as C
+    bz._lib.load().bz_alps_default_opts(C.byref(ao), 0)
+    with pytest.raises(bz.BazingaHipError):
+        prob.alps_solve(ao, po, np.zeros(n), np.zeros(n))
+    prob.slack = False
+    prob.close()

@@ -148,3 +148,34 @@ def test_golden_traces():
         assert a["gamma"] == b["gamma"]
         assert np.allclose(a["x"], b["x"], rtol=1e-12, atol=1e-14)
         assert np.allclose(a["z"], b["z"], rtol=1e-12, atol=1e-14)
+
+
+def test_als_rosenbrock_and_agrees_with_alps():
+    """ALS (src/algorithms/als.jl) in the oracle: the rosenbrock demo runs both solvers and expects the
+    same minimiser (0,0) (demo/rosenbrock.jl:131-136,186); on a convex problem ALS and ALPS agree."""
+    warnings.simplefilter("ignore")
+    sub = lambda **kw: R.PANOCplus(directions=R.LBFGS(5), maxit=10 ** 9, freq=10 ** 9, minimum_gamma=1e-32, **kw)
+    for x1 in (-5.0, -1.25, 2.5):
+        for x2 in (-3.75, 0.0, 5.0):
+            out = R.als(R.SmoothCostRosenbrock(10.0), R.NonsmoothCostRosenbrock(1.0), R.ConstraintRosenbrock(),
+                        R.SetRosenbrock(), np.array([x1, x2]), np.zeros(2), tol=1e-8, inner_tol=1.0,
+                        subsolver=sub, subsolver_maxit=10 ** 9)
+            assert out[5] == "first_order" and np.max(np.abs(out[0])) <= 1e-4
+    import bazinga_jl_amd as bz
+    n = 400
+    d = bz.synth.l1_quadratic(n)
+    orc = (R.DiagQuadratic(d["q"], d["b"]), R.NormL1(d["lam"]), R.IdentityFunction(), R.ClosedSet(R.IndBox(-1.0, 1.0)))
+    a, b = R.als(*orc, np.zeros(n), np.zeros(n)), R.alps(*orc, np.zeros(n), np.zeros(n))
+    assert a[5] == b[5] == "first_order" and np.max(np.abs(a[0] - b[0])) <= 1e-5
+    # slack gradient is the gradient of the slack value
+    rng = np.random.default_rng(0)
+    m = 24
+    mu, y, xs = rng.uniform(0.1, 1, m), rng.standard_normal(m), rng.standard_normal(2 * m)
+    F = R.AugLagFunSlack(R.DiagQuadratic(rng.uniform(0.1, 2, m), rng.standard_normal(m)), R.IdentityFunction(), mu, y, xs[:m])
+    g = np.empty(2 * m)
+    v = F.gradient(g, xs)
+    assert abs(v - F(xs)) <= 1e-12
+    for i in range(0, 2 * m, 5):
+        e = np.zeros(2 * m)
+        e[i] = 1e-6
+        assert abs((F(xs + e) - F(xs - e)) / 2e-6 - g[i]) <= 1e-6

@@ -931,31 +931,33 @@ __device__ __forceinline__ double grid_wait_fold_multi(const A& a, double* row, 
 // is consumed, and sched_barriers keep the compiler from sinking them back to their uses (with d
 // holding 160 of the 256 VGPRs its scheduler otherwise keeps only 2 loads in flight).  The first
 // group is loaded by persist_prefetch, which the kernel calls BEFORE waiting on the phase barrier.
-template <class T, int G, bool TWO>
+template <class T, int KR, int G, bool TWO>
 __device__ __forceinline__ void persist_prefetch(const T* __restrict__ p0, const T* __restrict__ p1,
                                                  int64_t first, int stride_e, Pack<T> (&pv)[G],
                                                  Pack<T> (&pw)[G]) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int64_t i0 = first + (int64_t)g * stride_e;
-        pv[g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
-        if (TWO) pw[g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+        if (g < KR) {
+            const int64_t i0 = first + (int64_t)g * stride_e;
+            pv[g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
+            if (TWO) pw[g] = *reinterpret_cast<const Pack<T>*>(p1 + i0);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// KR need not be a multiple of G: the last group is simply shorter (all bounds are compile-time).
 template <class T, int KR, int G, bool TWO, class F>
 __device__ __forceinline__ void persist_stream(const T* __restrict__ p0, const T* __restrict__ p1,
                                                int64_t first, int stride_e, Pack<T> (&pv)[G],
                                                Pack<T> (&pw)[G], F&& f) {
-    static_assert(KR % G == 0, "KR must be a multiple of the pipeline group");
     Pack<T> qv[G], qw[G];
 #pragma unroll
     for (int kb = 0; kb < KR; kb += G) {
         const bool even = ((kb / G) & 1) == 0;
-        if (kb + G < KR) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G; ++g) {
+            if (kb + G + g < KR) {
                 const int64_t i0 = first + (int64_t)(kb + G + g) * stride_e;
                 if (even) {
                     qv[g] = *reinterpret_cast<const Pack<T>*>(p0 + i0);
@@ -969,8 +971,10 @@ __device__ __forceinline__ void persist_stream(const T* __restrict__ p0, const T
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (even) f(kb + g, pv[g], TWO ? pw[g] : pv[g]);
-            else f(kb + g, qv[g], TWO ? qw[g] : qv[g]);
+            if (kb + g < KR) {
+                if (even) f(kb + g, pv[g], TWO ? pw[g] : pv[g]);
+                else f(kb + g, qv[g], TWO ? qw[g] : qv[g]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1010,7 +1014,7 @@ k_twoloop_persist(PersistArgs<T> a) {
 
     // phase 0: d = -res ; <s_0, d>
     double acc = 0.0;
-    persist_prefetch<T, G, true>(a.res, a.S[0], first, BZ_P_STRIDE, pv, pw);
+    persist_prefetch<T, KR, G, true>(a.res, a.S[0], first, BZ_P_STRIDE, pv, pw);
     persist_stream<T, KR, G, true>(a.res, a.S[0], first, BZ_P_STRIDE, pv, pw,
         [&](int k, const Pack<T>& r, const Pack<T>& s) {
 #pragma unroll
@@ -1025,7 +1029,7 @@ k_twoloop_persist(PersistArgs<T> a) {
         double* row = a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE;
         target += nb;
         grid_arrive(acc, row, a.counter, sh);
-        persist_prefetch<T, G, true>(a.Y[j], a.S[j + 1], first, BZ_P_STRIDE, pv, pw);
+        persist_prefetch<T, KR, G, true>(a.Y[j], a.S[j + 1], first, BZ_P_STRIDE, pv, pw);
         const double tot = phase_total(row);
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
@@ -1048,7 +1052,7 @@ k_twoloop_persist(PersistArgs<T> a) {
         double* row = a.parts + (size_t)(a.slot_loop1 + j) * PSTRIDE;
         target += nb;
         grid_arrive(acc, row, a.counter, sh);
-        persist_prefetch<T, G, false>(a.Y[j], a.Y[j], first, BZ_P_STRIDE, pv, pw);
+        persist_prefetch<T, KR, G, false>(a.Y[j], a.Y[j], first, BZ_P_STRIDE, pv, pw);
         const double tot = phase_total(row);
         const T al = T(tot) / a.ys[j];
         if (threadIdx.x == 0) alpha_sh[j] = al;
@@ -1073,7 +1077,7 @@ k_twoloop_persist(PersistArgs<T> a) {
         double* row = a.parts + (size_t)(a.slot_loop2 + j) * PSTRIDE;
         target += nb;
         grid_arrive(acc, row, a.counter, sh);
-        persist_prefetch<T, G, true>(a.S[j], a.Y[j - 1], first, BZ_P_STRIDE, pv, pw);
+        persist_prefetch<T, KR, G, true>(a.S[j], a.Y[j - 1], first, BZ_P_STRIDE, pv, pw);
         const double tot = phase_total(row);
         const T beta = T(tot) / a.ys[j];
         const T coef = alpha_sh[j] - beta;

@@ -152,7 +152,7 @@ template <class T> class Solver final : public SolverBase {
             // persistent two-loop: one 512-thread block per CU, KR register packs per thread; its vectors
             // are zero-padded to KR*num_cus*512 packs so that every round is in-bounds (no masks)
             const int64_t kneed = (nchunks + (int64_t)pblocks * PBLOCK - 1) / ((int64_t)pblocks * PBLOCK);
-            persist_kr = (kneed <= 40 && pblocks > 0 && pblocks <= PSTRIDE) ? (int)(4 * ((kneed + 3) / 4)) : 0;
+            persist_kr = (kneed <= 40 && pblocks > 0 && pblocks <= PSTRIDE) ? persist_round_kr((int)kneed) : 0;
             vcap = n;
             if (persist_kr) vcap = std::max<int64_t>(n, (int64_t)persist_kr * pblocks * PBLOCK * PackN<T>::N);
         }
@@ -900,16 +900,12 @@ template <class T> class Solver final : public SolverBase {
         }
         pbase += (unsigned long long)nphases * a.nb;
         switch (persist_kr) {
-        case 4: launch_persist(k_twoloop_persist<T, 4>, a); break;
-        case 8: launch_persist(k_twoloop_persist<T, 8>, a); break;
-        case 12: launch_persist(k_twoloop_persist<T, 12>, a); break;
-        case 16: launch_persist(k_twoloop_persist<T, 16>, a); break;
-        case 20: launch_persist(k_twoloop_persist<T, 20>, a); break;
-        case 24: launch_persist(k_twoloop_persist<T, 24>, a); break;
-        case 28: launch_persist(k_twoloop_persist<T, 28>, a); break;
-        case 32: launch_persist(k_twoloop_persist<T, 32>, a); break;
-        case 36: launch_persist(k_twoloop_persist<T, 36>, a); break;
-        default: launch_persist(k_twoloop_persist<T, 40>, a); break;
+#define BZ_KR_CASE(K) case K: launch_persist(k_twoloop_persist<T, K>, a); break;
+        BZ_KR_CASE(1) BZ_KR_CASE(2) BZ_KR_CASE(3) BZ_KR_CASE(4) BZ_KR_CASE(5) BZ_KR_CASE(6) BZ_KR_CASE(7) BZ_KR_CASE(8)
+        BZ_KR_CASE(10) BZ_KR_CASE(12) BZ_KR_CASE(14) BZ_KR_CASE(16) BZ_KR_CASE(20) BZ_KR_CASE(24) BZ_KR_CASE(28)
+        BZ_KR_CASE(32) BZ_KR_CASE(36) BZ_KR_CASE(40)
+#undef BZ_KR_CASE
+        default: throw Error(BZ_ERR_STATE, "persistent two-loop: no instantiation for this size");
         }
         slot_n[SL_LOOP2 + 0] = a.nb;
         t.in = D_.p; t.sgn = T(1); t.v = S_[order[0]].p; t.mode = 1; t.j = 0; t.apply_H = 0; t.H = T(1);
@@ -918,6 +914,13 @@ template <class T> class Solver final : public SolverBase {
         return t;
     }
     int persist_blocks() const { return pblocks; }
+    // register packs per thread: the smallest instantiated count >= the need (rounds past the need
+    // stream zero padding, so the steps are finer where the relative waste would be larger)
+    static int persist_round_kr(int kneed) {
+        static const int ks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40};
+        for (int k : ks) if (k >= kneed) return k;
+        return 0;
+    }
     template <class K> void launch_persist(K kernel, const PersistArgs<T>& a) {
         ProfRec r{C_PERSIST, nullptr, nullptr};
         if (prof_pick(C_PERSIST)) {

@@ -867,6 +867,7 @@ template <class T> class Solver final : public SolverBase {
         H = T(1);
     }
     void lbfgs_insert(T ys, T yty) {     // update!(H, s, y) when <s,y> > 0
+        if (M == 0) return;              // NoAcceleration: nothing is stored, H stays 1
         order.push_front(spare);
         ys_[spare] = ys;
         if ((int)order.size() > M) { spare = order.back(); order.pop_back(); }
@@ -982,8 +983,8 @@ template <class T> class Solver final : public SolverBase {
     // ------------------------------------------------ Base.iterate(iter)  (k = 1)
     void begin_dev(const bz_panoc_opts& o, const T* x0_dev) {
         opt = o;
-        if (o.lbfgs_memory < 1 || o.lbfgs_memory > MAX_MEM)
-            throw Error(BZ_ERR_ARG, "lbfgs_memory must be in 1..16");
+        if (o.lbfgs_memory < 0 || o.lbfgs_memory > MAX_MEM)
+            throw Error(BZ_ERR_ARG, "lbfgs_memory must be in 0..16 (0 = NoAcceleration)");
         if (o.max_backtracks < 1) throw Error(BZ_ERR_ARG, "max_backtracks must be >= 1");
         M = o.lbfgs_memory;
         alloc_history();

@@ -30,6 +30,12 @@ class LBFGS:
         self.memory = int(memory)
 
 
+class NoAcceleration:
+    """ProximalAlgorithms.NoAcceleration() (demo/rosenbrock.jl:96-97): plain forward-backward direction
+    d = -res; lowered as L-BFGS with an empty memory."""
+    memory = 0
+
+
 # ------------------------------------------------------------------ safeguards
 def default_dual_safeguard(y, cx=None):
     """src/utilities/safeguards.jl:2-10"""
@@ -137,8 +143,8 @@ class PANOCplus:
                  minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, persist=True,
                  ctx=None):
         self.directions = directions if directions is not None else LBFGS(5)
-        if not isinstance(self.directions, LBFGS):
-            raise UnsupportedOracle("only directions=LBFGS(M) is lowered to the device")
+        if not isinstance(self.directions, (LBFGS, NoAcceleration)):
+            raise UnsupportedOracle("only directions=LBFGS(M) and NoAcceleration() are lowered to the device")
         self.maxit, self.tol, self.verbose, self.freq = maxit, tol, verbose, freq
         self.minimum_gamma, self.alpha, self.beta = minimum_gamma, alpha, beta
         self.max_backtracks, self.fuse, self.persist, self.ctx = max_backtracks, fuse, persist, ctx

@@ -145,7 +145,7 @@ typedef struct {
     double  alpha;           /* default 0.95                                          */
     double  beta;            /* default 0.5                                           */
     int32_t max_backtracks;  /* default 20                                            */
-    int32_t lbfgs_memory;    /* directions = LBFGS(M), default 5                      */
+    int32_t lbfgs_memory;    /* directions = LBFGS(M), default 5; 0 = NoAcceleration() */
     int32_t fuse;            /* 1: use the single-pass fused kernel when the problem
                                 is separable (elementwise f, c = Identity); 0: always
                                 the generic kernel chain.  Results are bit-identical. */

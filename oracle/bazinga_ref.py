@@ -638,6 +638,25 @@ class LBFGS:
         self.memory = int(memory)
 
 
+class NoAcceleration:
+    """``NoAcceleration()`` directions (demo/rosenbrock.jl:96-97): d = -res, nothing to update."""
+
+
+class _NoAccelOperator:
+    currmem = 0
+    H = 1.0
+
+    def mul(self, d, v):
+        d[...] = v
+        return d
+
+    def update(self, s, y):
+        return _dot(s, y)
+
+    def reset(self):
+        pass
+
+
 class LBFGSOperator:
     """Two-loop L-BFGS operator with ring buffer of M pairs.
     update!: insert iff <s,y> > 0, H = ys/yty of the newest pair.
@@ -799,7 +818,8 @@ class PANOCplusIteration:
         g_z = self.g.prox(z, y, gamma)
         st = PANOCplusState(
             x=x, f_x=f_x, grad_f_x=grad_f_x, gamma=gamma, y=y, z=z, g_z=g_z, res=x - z,
-            H=LBFGSOperator(self.directions.memory, x),
+            H=(_NoAccelOperator() if isinstance(self.directions, NoAcceleration)
+               else LBFGSOperator(self.directions.memory, x)),
             x_prev=np.empty_like(x), res_prev=np.empty_like(x), d=np.empty_like(x),
             x_d=np.empty_like(x), grad_f_x_d=np.empty_like(x), z_curr=np.empty_like(x),
             grad_f_z=np.empty_like(x),

@@ -669,3 +669,22 @@ def test_lp_power_prox(bz, ref, g):
     assert a[5] == o[5]
     obj = lambda x: np.sum(x * (0.5 * d["q"] * x - d["b"])) + 0.8 * np.sum(np.maximum(x, 0) ** 0.5)
     assert abs(obj(a[0]) - obj(o[0])) <= 1e-6 * max(1.0, abs(obj(o[0])))
+
+
+def test_no_acceleration_direction(bz, ref):
+    """directions = NoAcceleration() (demo/rosenbrock.jl:96-97): d = -res; iterates follow the oracle."""
+    n = 20000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, directions=bz.NoAcceleration()).c_opts(), x0)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
+    it = ref.PANOCplusIteration(al, ref.NonsmoothCostFun(orc[1]), x0, directions=ref.NoAcceleration())
+    st = it.init()
+    for k in range(20):
+        assert rel(prob.panoc_vector("z"), st.z) <= RTOL_ITER
+        prob.panoc_step()
+        st = it.step(st)
+    assert prob.panoc_scalars()["lbfgs_mem"] == 0.0
+    prob.close()

@@ -451,51 +451,140 @@ k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, in
 //   The three reads of a row (as centre, north, south) hit L2/Infinity Cache: HBM sees x once.
 //   slots: +0 sum f terms, +1 sum t^2/mu.   f_only: skip the AL terms (alps.jl:39, f(x) alone).
 // ---------------------------------------------------------------------------
+// one pack of the stencil AL gradient; accF/accP accumulate the f and penalty terms of the valid lanes
+template <class T>
+__device__ __forceinline__ Pack<T> stencil_al_pack(const T* __restrict__ x, const ElemParams<T>& P, int64_t nx,
+                                                   int64_t ny, int f_only, int64_t i0, int cnt,
+                                                   const Pack<T>& xc, double& accF, double& accP) {
+    constexpr int N = PackN<T>::N;
+    const int64_t i = i0 / ny, j0 = i0 - i * ny;
+    Pack<T> xn = (i > 0) ? ld(x, i0 - ny, cnt) : splat(T(0));
+    Pack<T> xs = (i + 1 < nx) ? ld(x, i0 + ny, cnt) : splat(T(0));
+    const T west = (j0 > 0) ? x[i0 - 1] : T(0);
+    const T east = (j0 + N < ny) ? x[i0 + N] : T(0);
+    Pack<T> pb = ld(P.b, i0, cnt);
+    ElemLoads<T> L;
+    if (!f_only) load_params(P, i0, cnt, L, false, true, false);
+    Pack<T> pg;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const T c = xc.v[e];
+        const T w = (e == 0) ? west : xc.v[e > 0 ? e - 1 : 0];
+        const T ee = (e == N - 1) ? east : xc.v[e < N - 1 ? e + 1 : N - 1];
+        T Ax = T(4) * c;
+        Ax = Ax - w;
+        Ax = Ax - ee;
+        Ax = Ax - xn.v[e];
+        Ax = Ax - xs.v[e];
+        const T dfx = Ax - pb.v[e];
+        const T fterm = c * (T(0.5) * Ax - pb.v[e]);
+        T g = dfx, pterm = T(0);
+        if (!f_only) {
+            T t = c + L.muy.v[e];
+            T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e]);
+            t = t - sv;
+            pterm = (t * t) / L.mu.v[e];
+            T yupd = t / L.mu.v[e];
+            g = dfx + yupd;
+        }
+        pg.v[e] = g;
+        if (e < cnt) { accF += (double)fterm; accP += (double)pterm; }
+    }
+    return pg;
+}
+
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_algrad_stencil(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, int f_only,
                  T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
-    constexpr int N = PackN<T>::N;
     double acc[2] = {0.0, 0.0};
     BZ_FOR_EACH_CHUNK(T, n) {
         BZ_CHUNK_VARS(T, n)
-        const int64_t i = i0 / ny, j0 = i0 - i * ny;
         Pack<T> xc = ld(x, i0, cnt);
-        Pack<T> xn = (i > 0) ? ld(x, i0 - ny, cnt) : splat(T(0));
-        Pack<T> xs = (i + 1 < nx) ? ld(x, i0 + ny, cnt) : splat(T(0));
-        const T west = (j0 > 0) ? x[i0 - 1] : T(0);
-        const T east = (j0 + N < ny) ? x[i0 + N] : T(0);
-        Pack<T> pb = ld(P.b, i0, cnt);
-        ElemLoads<T> L;
-        if (!f_only) load_params(P, i0, cnt, L, false, true, false);
-        Pack<T> pg;
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const T c = xc.v[e];
-            const T w = (e == 0) ? west : xc.v[e > 0 ? e - 1 : 0];
-            const T ee = (e == N - 1) ? east : xc.v[e < N - 1 ? e + 1 : N - 1];
-            T Ax = T(4) * c;
-            Ax = Ax - w;
-            Ax = Ax - ee;
-            Ax = Ax - xn.v[e];
-            Ax = Ax - xs.v[e];
-            const T dfx = Ax - pb.v[e];
-            const T fterm = c * (T(0.5) * Ax - pb.v[e]);
-            T g = dfx, pterm = T(0);
-            if (!f_only) {
-                T t = c + L.muy.v[e];
-                T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e]);
-                t = t - sv;
-                pterm = (t * t) / L.mu.v[e];
-                T yupd = t / L.mu.v[e];
-                g = dfx + yupd;
-            }
-            pg.v[e] = g;
-            if (e < cnt) { acc[0] += (double)fterm; acc[1] += (double)pterm; }
-        }
+        Pack<T> pg = stencil_al_pack(x, P, nx, ny, f_only, i0, cnt, xc, acc[0], acc[1]);
         if (grad) st(grad, i0, cnt, pg);
     }
     block_reduce_store<2>(acc, 0u, parts, slot0);
+}
+
+// cfg-3 fast path, first half: gradient!(.., al, x_d) and the forward-backward step at x_d in one pass
+// (z_i depends only on x_d,i and gradL(x_d)_i).  Same arithmetic and summation order as
+// k_algrad_stencil followed by k_fbstep.  slots: slot_f +0 f terms, +1 t^2/mu ; slot_g +0 g terms,
+// +1 <g,res>, +2 ||res||^2
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_stencil_fb(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, T gamma,
+             T* __restrict__ grad, T* __restrict__ z, T* __restrict__ res, int64_t n,
+             double* __restrict__ parts, int slot_f, int slot_g) {
+    double accF[2] = {0.0, 0.0}, accG[3] = {0.0, 0.0, 0.0};
+    const T gl = gamma * P.g_lambda;
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> xc = ld(x, i0, cnt);
+        Pack<T> pg = stencil_al_pack(x, P, nx, ny, 0, i0, cnt, xc, accF[0], accF[1]);
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, false, false, true);
+        Pack<T> pz, pr;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T t = gamma * pg.v[e];
+            T y = xc.v[e] - t;
+            T gterm;
+            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            T r = xc.v[e] - zz;
+            pz.v[e] = zz; pr.v[e] = r;
+            if (e < cnt) {
+                accG[0] += (double)gterm;
+                accG[1] += (double)(pg.v[e] * r);
+                accG[2] += (double)(r * r);
+            }
+        }
+        st(grad, i0, cnt, pg);
+        st(z, i0, cnt, pz);
+        st(res, i0, cnt, pr);
+    }
+    block_reduce_store<2>(accF, 0u, parts, slot_f);
+    block_reduce_store<3>(accG, 0u, parts, slot_g);
+}
+
+// cfg-3 fast path, second half: gradient!(.., al, z) with the L-BFGS pair and the stopping norm in the
+// same pass (gradL(z) never goes to memory unless gz_out is given).  Same arithmetic and summation
+// order as k_algrad_stencil followed by k_update.  slots: slot_f +0,+1 ; slot_u +0 <s,y>, +1 <y,y>, +2 max
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_stencil_update(const T* __restrict__ zp, ElemParams<T> P, int64_t nx, int64_t ny,
+                 const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restrict__ res,
+                 const T* __restrict__ res_prev, const T* __restrict__ gx, T gamma,
+                 T* __restrict__ s_new, T* __restrict__ y_new, T* __restrict__ gz_out, int64_t n,
+                 double* __restrict__ parts, int slot_f, int slot_u) {
+    double accF[2] = {0.0, 0.0}, accU[3] = {0.0, 0.0, 0.0};
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> zc = ld(zp, i0, cnt);
+        Pack<T> pgz = stencil_al_pack(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1]);
+        Pack<T> px = ld(x, i0, cnt), pxp = ld(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ld(res_prev, i0, cnt);
+        Pack<T> pgx = ld(gx, i0, cnt), ps, py;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T sv = px.v[e] - pxp.v[e];
+            T yv = pr.v[e] - prp.v[e];
+            ps.v[e] = sv; py.v[e] = yv;
+            T w = pr.v[e] / gamma;
+            w = w - pgx.v[e];
+            w = w + pgz.v[e];
+            if (e < cnt) {
+                accU[0] += (double)(sv * yv);
+                accU[1] += (double)(yv * yv);
+                accU[2] = nanmax(accU[2], (double)(w < T(0) ? -w : w));
+            }
+        }
+        st(s_new, i0, cnt, ps);
+        st(y_new, i0, cnt, py);
+        if (gz_out) st(gz_out, i0, cnt, pgz);
+    }
+    block_reduce_store<2>(accF, 0u, parts, slot_f);
+    __syncthreads();
+    block_reduce_store<3>(accU, 4u, parts, slot_u);
 }
 
 // ---------------------------------------------------------------------------

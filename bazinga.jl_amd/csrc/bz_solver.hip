@@ -1102,7 +1102,22 @@ template <class T> class Solver final : public SolverBase {
             // x_d = x + d ; gradient at x_d ; state.x = x_d
             launch(C_TWOLOOP, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
                    parts_.p, 0);
-            algrad(X_[xd].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+            if (desc.f_kind == BZ_F_STENCIL5 && opt.fuse && !lp_g && !slack && !ctx->multi()) {
+                // stencil fast path: {AL gradient at x_d + FB step} and {AL gradient at z + pair + stop norm}
+                // as two passes; same partial sums as the four generic kernels of the first trial
+                for (int sidx = SL_FXD; sidx <= SL_STOP; ++sidx) slot_n[sidx] = grid;
+                launch(C_ALGRAD, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
+                       (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
+                       (int)SL_GSUM);
+                launch(C_ALGRAD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
+                       (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
+                       (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, (T*)nullptr, n, parts_.p,
+                       (int)SL_FZ, (int)SL_YS);
+                have_trial = true; gx_valid = true; gz_valid = false;
+                n_grad += 2; n_prox += 1;
+            } else {
+                algrad(X_[xd].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+            }
         }
         T sigma = beta * (T(0.5) / gamma) * (T(1) - alpha);
         const T tol0 = T(10) * eps * (T(1) + std::abs(FBE_x));

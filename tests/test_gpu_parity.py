@@ -688,3 +688,23 @@ def test_no_acceleration_direction(bz, ref):
         st = it.step(st)
     assert prob.panoc_scalars()["lbfgs_mem"] == 0.0
     prob.close()
+
+
+def test_stencil_fast_path_equals_generic_bitwise(bz, ref):
+    """cfg 3: the two fused stencil passes ({gradL(x_d) + FB step}, {gradL(z) + pair + stop norm}) are the
+    same arithmetic and the same summation order as the four generic kernels."""
+    nx, ny = 96, 128
+    d, n, dev, orc = make_cfg3(bz, ref, nx, ny, load=-1.0)
+    out = []
+    for fuse in (True, False):
+        prob = bz.Problem(*dev, n, n, np.float64)
+        prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse, minimum_gamma=2.3e-16).c_opts(), d["x0"])
+        for _ in range(30):
+            prob.panoc_step()
+        out.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars()))
+        prob.close()
+    (x1, z1, r1, s1), (x2, z2, r2, s2) = out
+    assert np.array_equal(x1, x2) and np.array_equal(z1, z2) and np.array_equal(r1, r2)
+    for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "al_z"):
+        assert s1[key] == s2[key], key

@@ -1672,8 +1672,10 @@ struct CollectArgs {
     ScalarSrc src[MAX_COLLECT];
     unsigned maxmask;
     int n;
+    double ticket;      // sequence number of this read-back
 };
-// one block per source: fold it and write the scalar to (host-mapped) `out`
+// one block per source: fold it and write {scalar, ticket} to the (host-mapped) mailbox `out`; the host
+// spins on the tickets instead of paying a blocking stream synchronisation
 __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out);
 
 // multi-GPU: fold the block partials of slots [first, first+cnt) into send[first+i]

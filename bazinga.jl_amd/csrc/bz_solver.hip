@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -78,7 +79,11 @@ __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out) {
     __shared__ double sh[WAVES];
     const int i = blockIdx.x;
     double t = fold_src(a.src[i], (a.maxmask >> i) & 1u, sh);
-    if (threadIdx.x == 0) out[i] = t;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(out + 2 * i, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();                       // value before ticket
+        __hip_atomic_store(out + 2 * i + 1, a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -237,7 +242,8 @@ template <class T> class Solver final : public SolverBase {
         alphas_.alloc(MAX_MEM + 1);
         send_.alloc(SL_COUNT);
         recv_.alloc((size_t)SL_COUNT * std::max(1, ctx->nranks));
-        BZ_HIP(hipHostMalloc((void**)&host_out_, sizeof(double) * MAX_COLLECT, hipHostMallocMapped));
+        BZ_HIP(hipHostMalloc((void**)&host_out_, sizeof(double) * 2 * MAX_COLLECT, hipHostMallocMapped));
+        std::memset(host_out_, 0, sizeof(double) * 2 * MAX_COLLECT);
         BZ_HIP(hipHostGetDevicePointer((void**)&host_out_dev_, host_out_, 0));
         BZ_HIP(hipHostMalloc((void**)&ptimeout_, sizeof(int), hipHostMallocMapped));
         *ptimeout_ = 0;
@@ -561,8 +567,9 @@ template <class T> class Solver final : public SolverBase {
     bool persist_ok = false;
     std::vector<DBuf<T>> S_, Y_;
     DBuf<double> parts_, alphas_, send_, recv_;
-    double* host_out_ = nullptr;
+    double* host_out_ = nullptr;             // pinned mailbox: {value, ticket} per collected scalar
     double* host_out_dev_ = nullptr;
+    unsigned long long collect_seq = 0;
     int grp_first[SL_COUNT], grp_cnt[SL_COUNT];
     int slot_n[SL_COUNT];                    // number of valid block partials per slot
 
@@ -695,8 +702,26 @@ template <class T> class Solver final : public SolverBase {
             a.src[a.n] = src(s);
             ++a.n;
         }
+        a.ticket = (double)(++collect_seq);
         launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
-        BZ_HIP(hipStreamSynchronize(ctx->stream));
+        // spin on the tickets in pinned host memory (a few microseconds after the kernel's stores land);
+        // bounded: on a fault or a hang fall through to the blocking synchronisation, which reports it
+        {
+            volatile double* ho = host_out_;
+            const auto t_start = std::chrono::steady_clock::now();
+            bool done = false;
+            for (unsigned spin = 0; !done; ++spin) {
+                done = true;
+                for (int i = 0; i < a.n; ++i)
+                    if (ho[2 * i + 1] != a.ticket) { done = false; break; }
+                if (!done && (spin & 0x3FFu) == 0x3FFu) {
+                    if (hipStreamQuery(ctx->stream) != hipErrorNotReady) break;     // finished or failed
+                    if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) break;
+                }
+            }
+            if (!done) BZ_HIP(hipStreamSynchronize(ctx->stream));
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         if (*ptimeout_) {
             const int code = *ptimeout_;
             *ptimeout_ = 0;
@@ -705,7 +730,9 @@ template <class T> class Solver final : public SolverBase {
                         : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
                                     : "persistent two-loop kernel: p2p phase exchange timed out waiting for a peer rank");
         }
-        return std::vector<double>(host_out_, host_out_ + a.n);
+        std::vector<double> out(a.n);
+        for (int i = 0; i < a.n; ++i) out[i] = host_out_[2 * i];
+        return out;
     }
 
     // forward-backward step kernel; the Newton/pow prox kinds use their own instantiation so the

@@ -1098,7 +1098,9 @@ k_twoloop_persist(PersistArgs<T> a) {
     // branches.  The element stride between a thread's packs is re-read per phase through a volatile
     // LDS pointer so the KR pack offsets are not hoisted out of the phase loops (2 VGPRs each).
 #define BZ_P_STRIDE (*(volatile int*)&stride_sh)
-    constexpr int G = 4;
+    // pipeline depth: 4 rounds per group; 2 above 40 packs so that d may take up to 192 of the 256 VGPRs
+    // (48 packs: 12.58 M doubles per GPU, one BASELINE config-5 shard)
+    constexpr int G = KR > 40 ? 2 : 4;
     Pack<T> pv[G], pw[G];      // first group of the coming phase, loaded across the phase barrier
 
     // phase 0: d = -res ; <s_0, d>

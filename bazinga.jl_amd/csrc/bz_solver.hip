@@ -157,7 +157,7 @@ template <class T> class Solver final : public SolverBase {
             // persistent two-loop: one 512-thread block per CU, KR register packs per thread; its vectors
             // are zero-padded to KR*num_cus*512 packs so that every round is in-bounds (no masks)
             const int64_t kneed = (nchunks + (int64_t)pblocks * PBLOCK - 1) / ((int64_t)pblocks * PBLOCK);
-            persist_kr = (kneed <= 40 && pblocks > 0 && pblocks <= PSTRIDE) ? persist_round_kr((int)kneed) : 0;
+            persist_kr = (kneed <= 48 && pblocks > 0 && pblocks <= PSTRIDE) ? persist_round_kr((int)kneed) : 0;
             vcap = n;
             if (persist_kr) vcap = std::max<int64_t>(n, (int64_t)persist_kr * pblocks * PBLOCK * PackN<T>::N);
         }
@@ -931,7 +931,7 @@ template <class T> class Solver final : public SolverBase {
 #define BZ_KR_CASE(K) case K: launch_persist(k_twoloop_persist<T, K>, a); break;
         BZ_KR_CASE(1) BZ_KR_CASE(2) BZ_KR_CASE(3) BZ_KR_CASE(4) BZ_KR_CASE(5) BZ_KR_CASE(6) BZ_KR_CASE(7) BZ_KR_CASE(8)
         BZ_KR_CASE(10) BZ_KR_CASE(12) BZ_KR_CASE(14) BZ_KR_CASE(16) BZ_KR_CASE(20) BZ_KR_CASE(24) BZ_KR_CASE(28)
-        BZ_KR_CASE(32) BZ_KR_CASE(36) BZ_KR_CASE(40)
+        BZ_KR_CASE(32) BZ_KR_CASE(36) BZ_KR_CASE(40) BZ_KR_CASE(44) BZ_KR_CASE(48)
 #undef BZ_KR_CASE
         default: throw Error(BZ_ERR_STATE, "persistent two-loop: no instantiation for this size");
         }
@@ -945,7 +945,7 @@ template <class T> class Solver final : public SolverBase {
     // register packs per thread: the smallest instantiated count >= the need (rounds past the need
     // stream zero padding, so the steps are finer where the relative waste would be larger)
     static int persist_round_kr(int kneed) {
-        static const int ks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40};
+        static const int ks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 44, 48};
         for (int k : ks) if (k >= kneed) return k;
         return 0;
     }

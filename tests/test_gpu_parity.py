@@ -708,3 +708,48 @@ def test_stencil_fast_path_equals_generic_bitwise(bz, ref):
     assert np.array_equal(x1, x2) and np.array_equal(z1, z2) and np.array_equal(r1, r2)
     for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "al_z"):
         assert s1[key] == s2[key], key
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_kinds_alps_parity(bz, ref, seed):
+    """Seeded sweep over the lowered oracle kinds and ragged sizes: the device ALPS and the oracle ALPS take
+    the same outer/inner iteration counts (up to a late branch flip) and return the same point."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 6000))
+    q = rng.uniform(0.2, 5.0, n)
+    b = rng.standard_normal(n) * 4
+    fk = rng.choice(["diag", "zero"], p=[0.8, 0.2])
+    gk = rng.choice(["l1", "nonneg", "l1box", "l0box", "indbox", "zero"])
+    Dk = rng.choice(["box", "free", "zero"]) if fk == "diag" else "box"
+    lam = float(rng.uniform(0.1, 3.0))
+    u = rng.uniform(0.0, 1.5, n)
+    f_d, f_r = (bz.DiagQuadratic(q, b), ref.DiagQuadratic(q, b)) if fk == "diag" else (bz.Zero(), ref.Zero())
+    g_d, g_r = {"l1": (bz.NormL1(lam), ref.NormL1(lam)),
+                "nonneg": (bz.NormL1Nonneg(lam), ref.NormL1Nonneg(lam)),
+                "l1box": (bz.NormL1Box(lam, u=u), ref.NormL1Box(lam, u=u)),
+                "l0box": (bz.NormL0Box(lam, u=u), ref.NormL0Box(lam, u=u)),
+                "indbox": (bz.IndBox(-0.7, 0.9), ref.IndBox(-0.7, 0.9)),
+                "zero": (bz.Zero(), ref.Zero())}[gk]
+    lo, hi = -float(rng.uniform(0.2, 1.0)), float(rng.uniform(0.2, 1.0))
+    D_d, D_r = {"box": (bz.ClosedSet(bz.IndBox(lo, hi)), ref.ClosedSet(ref.IndBox(lo, hi))),
+                "free": (bz.FreeSet(), ref.FreeSet()), "zero": (bz.ZeroSet(), ref.ZeroSet())}[Dk]
+    x0, y0 = rng.standard_normal(n) * 0.1, rng.standard_normal(n) * 0.1
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = ref.alps(f_r, g_r, ref.IdentityFunction(), D_r, x0, y0, maxit=40)
+    a = bz.alps(f_d, g_d, bz.IdentityFunction(), D_d, x0, y0, maxit=40)
+    tag = f"n={n} f={fk} g={gk} D={Dk}"
+    assert a[5] == o[5], tag
+    assert a[2] == o[2], tag
+    # Subproblems that need ~1000 inner iterations are sensitive to the rounding of the reduced scalars:
+    # the oracle run twice with two summation roundings (LongDoubleReducer) differs by 12 % in the inner
+    # count and 2e-6 in x on these cases (SURVEY §7 H3), so that is the resolution of the comparison there.
+    long_run = o[3] > 500
+    assert abs(a[3] - o[3]) <= max(3, (0.25 if long_run else 0.05) * o[3]), tag
+    scale = max(1.0, float(np.max(np.abs(o[0]))))
+    tol = (2e-5 if long_run else 1e-6) if gk != "l0box" else 1e-4   # L0 prox is discontinuous: a tie may flip an entry
+    if gk == "l0box":
+        assert np.mean(np.abs(a[0] - o[0]) <= tol * scale) >= 0.999, tag
+    else:
+        assert np.max(np.abs(a[0] - o[0])) <= tol * scale, tag

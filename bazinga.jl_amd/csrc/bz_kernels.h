@@ -806,7 +806,7 @@ k_gemv_t_finish(const T* __restrict__ part, int nchunks, int64_t pstride, const 
 struct P2PWords {            // device view of bz::P2PMailbox (bz_solver.h); same layout
     double pval[2][8];
     unsigned long long pflag[2][8];
-    double xval[2][8][16];
+    double xval[2][8][32];
     unsigned long long xflag[2][8];
 };
 __device__ __forceinline__ void sys_store(double* p, double v) {
@@ -827,7 +827,7 @@ constexpr unsigned XSPIN_LIMIT = 20000000u;
 // leave every rank's pack in recv[r*cnt + i] (the layout ScalarSrc{recv, nranks, cnt} expects)
 struct XchgArgs {
     const double* parts;
-    int counts[16];          // valid block partials per slot
+    int counts[32];          // valid block partials per slot
     int first, cnt;
     unsigned maxmask;
     int rank, nranks;
@@ -839,7 +839,7 @@ struct XchgArgs {
 };
 static __global__ void __launch_bounds__(BLOCK) k_exchange(XchgArgs a) {
     __shared__ double sh[WAVES];
-    __shared__ double vals[16];
+    __shared__ double vals[32];
     for (int i = 0; i < a.cnt; ++i) {
         ScalarSrc s{a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts[i], 1};
         const double t = fold_src(s, (a.maxmask >> i) & 1u, sh);
@@ -1464,6 +1464,231 @@ k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_pr
 }
 
 // ---------------------------------------------------------------------------
+// Compact (Byrd-Nocedal-Schnabel) form of the L-BFGS operator: all 2m inner products with v = -res are
+// independent, so d = H(-res) needs ONE reduction phase instead of 2m sequential ones:
+//     p = S'v, w = Y'v ; u1 = M1 p - H0 M2' w ; u2 = -M2 p ; d = H0 v + S u1 + H0 Y u2
+// with M1 = R^-T (D + H0 Y'Y) R^-1, M2 = R^-1 (m x m, maintained by the host from the Gram products the
+// kernels return).  Same operator as the two-loop recursion (oracle: LBFGSCompactOperator); used when x is
+// sharded over several GPUs, where each reduction phase is a cross-GPU exchange.  MM = compile-time
+// capacity (pairs are ordered oldest -> newest).
+// ---------------------------------------------------------------------------
+template <class T, int MM> struct CompactVecs {
+    const T* S[MM];
+    const T* Y[MM];
+    int m;
+};
+template <int MM> struct CompactCoef {
+    double M1[MM * MM];
+    double M2[MM * MM];
+    double H0;
+    ScalarSrc psrc[2 * MM];      // p_0..p_{MM-1}, w_0..w_{MM-1}
+};
+
+// K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* __restrict__ parts,
+            int slot0) {
+    double acc[2 * MM];
+#pragma unroll
+    for (int k = 0; k < 2 * MM; ++k) acc[k] = 0.0;
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pr = ld(res, i0, cnt);
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {
+            if (i < V.m) {
+                Pack<T> ps = ld(V.S[i], i0, cnt), py = ld(V.Y[i], i0, cnt);
+#pragma unroll
+                for (int e = 0; e < PackN<T>::N; ++e)
+                    if (e < cnt) {
+                        const T v = T(-1) * pr.v[e];
+                        acc[i] += (double)(ps.v[e] * v);
+                        acc[MM + i] += (double)(py.v[e] * v);
+                    }
+            }
+        }
+    }
+    block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
+}
+
+// fold 2*MM scalar sources at once: wave w folds sources w, w+4, ... (fixed order), results in sh_out
+template <int MM>
+__device__ __forceinline__ void fold_many(const ScalarSrc* srcs, int m, double* sh_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < 2 * MM; k += WAVES) {
+        const int idx = k < MM ? k : k - MM;
+        double v = 0.0;
+        if (idx < m) {
+            const ScalarSrc s = srcs[k];
+            for (int i = lane; i < s.count; i += 64) v += s.p[(size_t)i * s.stride];
+            v = wave_sum(v);
+        }
+        if (lane == 0) sh_out[k] = v;
+    }
+    __syncthreads();
+}
+
+// coefficients of the compact form for this application: every block computes the same bits
+template <class T, int MM>
+__device__ __forceinline__ void compact_coefs(const CompactCoef<MM>& C, int m, T (&u1)[MM], T (&u2h)[MM]) {
+    __shared__ double pw[2 * MM];
+    __shared__ double us[2 * MM];
+    fold_many<MM>(C.psrc, m, pw);
+    if (threadIdx.x < MM) {
+        const int i = threadIdx.x;
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int j = 0; j < m; ++j) a += C.M1[i * MM + j] * pw[j];
+        for (int j = 0; j < m; ++j) b += C.M2[j * MM + i] * pw[MM + j];
+        for (int j = 0; j < m; ++j) c += C.M2[i * MM + j] * pw[j];
+        us[i] = (i < m) ? a - C.H0 * b : 0.0;
+        us[MM + i] = (i < m) ? C.H0 * (-c) : 0.0;          // H0 * u2_i
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MM; ++i) { u1[i] = (T)us[i]; u2h[i] = (T)us[MM + i]; }
+}
+
+// d for one pack:  d = H0 v + sum u1_i s_i + sum (H0 u2_i) y_i ,  v = -res
+template <class T, int MM>
+__device__ __forceinline__ void compact_d(const CompactVecs<T, MM>& V, T H0, const T (&u1)[MM],
+                                          const T (&u2h)[MM], const Pack<T>& pres, const Pack<T> (&ps)[MM],
+                                          const Pack<T> (&py)[MM], Pack<T>& d) {
+#pragma unroll
+    for (int e = 0; e < PackN<T>::N; ++e) {
+        T a = H0 * (T(-1) * pres.v[e]);
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+            if (i < V.m) { T t = u1[i] * ps[i].v[e]; a = a + t; }
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+            if (i < V.m) { T t = u2h[i] * py[i].v[e]; a = a + t; }
+        d.v[e] = a;
+    }
+}
+
+// x_d = x + H(-res) in compact form (generic path: stencil / dense / fuse = 0)
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_compact_xd(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ res,
+             const T* __restrict__ x, T* __restrict__ x_d, int64_t n) {
+    T u1[MM], u2h[MM];
+    compact_coefs<T, MM>(C, V.m, u1, u2h);
+    const T H0 = (T)C.H0;
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pres = ld(res, i0, cnt), px = ld(x, i0, cnt), ps[MM], py[MM], d, o;
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+            if (i < V.m) { ps[i] = ld(V.S[i], i0, cnt); py[i] = ld(V.Y[i], i0, cnt); }
+        compact_d<T, MM>(V, H0, u1, u2h, pres, ps, py, d);
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) o.v[e] = px.v[e] + d.v[e];
+        st(x_d, i0, cnt, o);
+    }
+}
+
+// Gram products of a (new) pair with the stored ones: <s_i, y_new> -> slot0 + i, <y_i, y_new> -> slot0 + MM + i
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double* __restrict__ parts,
+            int slot0) {
+    double acc[2 * MM];
+#pragma unroll
+    for (int k = 0; k < 2 * MM; ++k) acc[k] = 0.0;
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        Pack<T> pn = ld(y_new, i0, cnt);
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {
+            if (i < V.m) {
+                Pack<T> ps = ld(V.S[i], i0, cnt), py = ld(V.Y[i], i0, cnt);
+#pragma unroll
+                for (int e = 0; e < PackN<T>::N; ++e)
+                    if (e < cnt) {
+                        acc[i] += (double)(ps.v[e] * pn.v[e]);
+                        acc[MM + i] += (double)(py.v[e] * pn.v[e]);
+                    }
+            }
+        }
+    }
+    block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
+}
+
+// The separable fast path with the compact direction: ONE pass computes d from (res, S, Y), then x_d, both AL
+// gradients, the FB step, the new pair, its Gram products with the stored pairs and the stop norm.
+//   reads : res, S[m], Y[m], x, q, b, mu, mu*y   writes: x_d, z, res, s_new, y_new
+//   slots : slot0 + 0..9 as k_fused_sep ; + 10 + i: <s_i, y_new> ; + 10 + MM + i: <y_i, y_new>
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
+                const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
+                T* __restrict__ z, T* __restrict__ res, T* __restrict__ s_new, T* __restrict__ y_new,
+                int64_t n, double* __restrict__ parts, int slot0) {
+    T u1[MM], u2h[MM];
+    compact_coefs<T, MM>(C, V.m, u1, u2h);
+    const T H0 = (T)C.H0;
+    const T gl = gamma * P.g_lambda;
+    double acc[10 + 2 * MM];
+#pragma unroll
+    for (int k = 0; k < 10 + 2 * MM; ++k) acc[k] = 0.0;
+    BZ_FOR_EACH_CHUNK(T, n) {
+        BZ_CHUNK_VARS(T, n)
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, true, true, true);
+        Pack<T> px = ld(x, i0, cnt), prp = ld(res_prev, i0, cnt), ps[MM], py[MM], d;
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+            if (i < V.m) { ps[i] = ld(V.S[i], i0, cnt); py[i] = ld(V.Y[i], i0, cnt); }
+        compact_d<T, MM>(V, H0, u1, u2h, prp, ps, py, d);
+        Pack<T> pxd, pz, pr, pss, pyy;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T xd = px.v[e] + d.v[e];
+            ALOut<T> o1 = al_elem(P.f_kind, P.D_kind, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+            T t = gamma * o1.grad;
+            T y = xd - t;
+            T gterm;
+            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            T r = xd - zz;
+            ALOut<T> o2 = al_elem(P.f_kind, P.D_kind, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+            T sv = xd - px.v[e];
+            T yy = r - prp.v[e];
+            T w = r / gamma;
+            w = w - o1.grad;
+            w = w + o2.grad;
+            pxd.v[e] = xd; pz.v[e] = zz; pr.v[e] = r; pss.v[e] = sv; pyy.v[e] = yy;
+            if (e < cnt) {
+                acc[0] += (double)o1.fterm;
+                acc[1] += (double)o1.pterm;
+                acc[2] += (double)gterm;
+                acc[3] += (double)(o1.grad * r);
+                acc[4] += (double)(r * r);
+                acc[5] += (double)o2.fterm;
+                acc[6] += (double)o2.pterm;
+                acc[7] += (double)(sv * yy);
+                acc[8] += (double)(yy * yy);
+                acc[9] = nanmax(acc[9], (double)(w < T(0) ? -w : w));
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < V.m) {
+                        acc[10 + i] += (double)(ps[i].v[e] * yy);
+                        acc[10 + MM + i] += (double)(py[i].v[e] * yy);
+                    }
+            }
+        }
+        st(x_d, i0, cnt, pxd);
+        st(z, i0, cnt, pz);
+        st(res, i0, cnt, pr);
+        st(s_new, i0, cnt, pss);
+        st(y_new, i0, cnt, pyy);
+    }
+    block_reduce_store<10 + 2 * MM>(acc, 1u << 9, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------
 // K6: x = tau*x_d + (1-tau)*z_curr
@@ -1669,7 +1894,7 @@ k_fvalue_elem(const T* __restrict__ x, ElemParams<T> P, int64_t n, double* __res
 // ---------------------------------------------------------------------------
 // scalar plumbing
 // ---------------------------------------------------------------------------
-constexpr int MAX_COLLECT = 24;
+constexpr int MAX_COLLECT = 40;
 struct CollectArgs {
     ScalarSrc src[MAX_COLLECT];
     unsigned maxmask;

@@ -42,7 +42,7 @@ struct Error : std::runtime_error {
 // ranks map through HIP IPC; scalars are exchanged by system-scope stores straight into the peers'
 // mailboxes over xGMI, tagged with a sequence number — no collective library call, no host involvement.
 constexpr int P2P_MAXRANKS = 8;
-constexpr int P2P_PACK = 16;               // doubles per pack exchange
+constexpr int P2P_PACK = 32;               // doubles per pack exchange
 struct P2PMailbox {                        // layout of one rank's mailbox (all words written by peers)
     double pval[2][P2P_MAXRANKS];                          // persistent-kernel phase totals
     unsigned long long pflag[2][P2P_MAXRANKS];
@@ -94,12 +94,15 @@ enum Slot : int {
     SL_TRIAL = 32,     // 10 slots of the fused kernel / trial sequence
     SL_FXD = 32, SL_PXD = 33, SL_GSUM = 34, SL_DOT = 35, SL_SS = 36,
     SL_FZ = 37, SL_PZ = 38, SL_YS = 39, SL_YTY = 40, SL_STOP = 41,
-    SL_AUX = 42,       // 2 slots: Lipschitz estimate / misc
-    SL_OUTER = 44,     // 2 slots: outer loop
-    SL_SCRATCH = 46,   // sink for partials nobody reads
-    SL_COUNT = 47
+    SL_GU = 42,        // compact L-BFGS: Gram products of the new pair, 2*CM slots right behind the trial slots
+    SL_AUX = 52,       // 2 slots: Lipschitz estimate / misc
+    SL_OUTER = 54,     // 2 slots: outer loop
+    SL_SCRATCH = 56,   // sink for partials nobody reads
+    SL_GP = 57,        // compact L-BFGS: p = S'v, w = Y'v, 2*CM slots
+    SL_COUNT = 67
 };
 constexpr int MAX_MEM = 16;
+constexpr int CM = 5;            // capacity of the compact L-BFGS form (pairs)
 
 struct SolverBase {
     virtual ~SolverBase() = default;

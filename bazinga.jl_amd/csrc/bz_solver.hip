@@ -592,6 +592,10 @@ template <class T> class Solver final : public SolverBase {
     int spare = 0;
     T ys_[MAX_MEM + 1];
     T H = T(1);
+    // compact form: Gram products of the stored pairs in logical order (oldest first), CM x CM
+    bool compact_ok = false;
+    int gm = 0;
+    double Gsy[CM * CM], Gyy[CM * CM];
 
     // profiling
     struct ProfRec { int cat; hipEvent_t a, b; };
@@ -883,18 +887,91 @@ template <class T> class Solver final : public SolverBase {
         for (int i = 0; i <= M; ++i) { S_[i].alloc(vcap); Y_[i].alloc(vcap); }
     }
     void lbfgs_reset_all() {
+        gm = 0;
         order.clear(); freeslots.clear();
         spare = 0;
         for (int i = M; i >= 1; --i) freeslots.push_back(i);
         H = T(1);
     }
     void lbfgs_reset() {                 // reset!(H): currmem = curridx = 0, H = 1
+        gm = 0;
         for (int s : order) freeslots.push_back(s);
         order.clear();
         H = T(1);
     }
-    void lbfgs_insert(T ys, T yty) {     // update!(H, s, y) when <s,y> > 0
+    // Gram products of the stored pairs after inserting a pair whose products with them are sy[i], yy[i]
+    // (i = logical index, oldest first): drop the oldest when the ring is full, append row/column
+    void gram_insert(double* sy, double* yy, double ys, double yty) {
+        int m = gm;
+        if (m == M) {                    // the oldest pair is overwritten
+            for (int i = 1; i < m; ++i)
+                for (int j = 1; j < m; ++j) { Gsy[(i - 1) * CM + (j - 1)] = Gsy[i * CM + j]; Gyy[(i - 1) * CM + (j - 1)] = Gyy[i * CM + j]; }
+            for (int i = 1; i < m; ++i) { sy[i - 1] = sy[i]; yy[i - 1] = yy[i]; }
+            --m;
+        }
+        for (int i = 0; i < m; ++i) {
+            Gsy[i * CM + m] = sy[i]; Gsy[m * CM + i] = 0.0;
+            Gyy[i * CM + m] = yy[i]; Gyy[m * CM + i] = yy[i];
+        }
+        Gsy[m * CM + m] = ys; Gyy[m * CM + m] = yty;
+        gm = m + 1;
+    }
+    // M1 = R^-T (D + H0 Y'Y) R^-1 and M2 = R^-1 (same loops as LBFGSCompactOperator.coefficient_matrices)
+    void compact_matrices(double H0, double* M1, double* M2) const {
+        const int m = gm;
+        double Ri[CM * CM] = {0}, B[CM * CM] = {0}, T1[CM * CM] = {0};
+        for (int j = 0; j < m; ++j) {
+            Ri[j * CM + j] = 1.0 / Gsy[j * CM + j];
+            for (int i = j - 1; i >= 0; --i) {
+                double acc = 0.0;
+                for (int k = i + 1; k <= j; ++k) acc += Gsy[i * CM + k] * Ri[k * CM + j];
+                Ri[i * CM + j] = -acc / Gsy[i * CM + i];
+            }
+        }
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) B[i * CM + j] = H0 * Gyy[i * CM + j] + (i == j ? Gsy[i * CM + i] : 0.0);
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k <= j; ++k) acc += B[i * CM + k] * Ri[k * CM + j];
+                T1[i * CM + j] = acc;
+            }
+        for (int i = 0; i < CM * CM; ++i) { M1[i] = 0.0; M2[i] = Ri[i]; }
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k <= i; ++k) acc += Ri[k * CM + i] * T1[k * CM + j];
+                M1[i * CM + j] = acc;
+            }
+    }
+    CompactVecs<T, CM> compact_vecs() const {      // logical (oldest first) view of the physical ring
+        CompactVecs<T, CM> V;
+        std::memset(&V, 0, sizeof(V));
+        V.m = (int)order.size();
+        for (int i = 0; i < V.m; ++i) { V.S[i] = S_[order[V.m - 1 - i]].p; V.Y[i] = Y_[order[V.m - 1 - i]].p; }
+        return V;
+    }
+    // p = S'(-res), w = Y'(-res) and the coefficient block for the kernels that apply the operator
+    CompactCoef<CM> compact_prepare(const CompactVecs<T, CM>& V) {
+        for (int k = 0; k < 2 * CM; ++k) slot_n[SL_GP + k] = grid;
+        launch(C_DOT, k_gram_dots<T, CM>, grid, V, (const T*)RES_[rc].p, n, parts_.p, (int)SL_GP);
+        gather(SL_GP, 2 * CM, 0u);
+        CompactCoef<CM> C;
+        std::memset(&C, 0, sizeof(C));
+        C.H0 = (double)H;
+        compact_matrices(C.H0, C.M1, C.M2);
+        for (int k = 0; k < 2 * CM; ++k) C.psrc[k] = src(SL_GP + k);
+        return C;
+    }
+
+    void lbfgs_insert(T ys, T yty, const double* sy = nullptr, const double* yy = nullptr) {     // update!(H, s, y) when <s,y> > 0
         if (M == 0) return;              // NoAcceleration: nothing is stored, H stays 1
+        if (compact_ok) {
+            double z[CM] = {0};
+            double a[CM], b[CM];
+            for (int i = 0; i < CM; ++i) { a[i] = sy ? sy[i] : z[i]; b[i] = yy ? yy[i] : z[i]; }
+            gram_insert(a, b, (double)ys, (double)yty);
+        }
         order.push_front(spare);
         ys_[spare] = ys;
         if ((int)order.size() > M) { spare = order.back(); order.pop_back(); }
@@ -1016,6 +1093,8 @@ template <class T> class Solver final : public SolverBase {
         M = o.lbfgs_memory;
         alloc_history();
         lbfgs_reset_all();
+        if (o.lbfgs_compact && M > CM) throw Error(BZ_ERR_ARG, "lbfgs_compact supports lbfgs_memory <= 5");
+        compact_ok = o.lbfgs_compact && M >= 1;
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
         fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
@@ -1111,14 +1190,28 @@ template <class T> class Solver final : public SolverBase {
         const T FBE_x = (f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr0 * nr0)) + g_z;
         fbe_last = FBE_x;
         // direction d = H(-res): all but the last axpy
-        const bool use_persist = persist_ok && !order.empty();
-        TailArgs<T> tail = use_persist ? two_loop_persist() : two_loop();
+        const bool use_compact = compact_ok && !order.empty();
+        const bool use_persist = persist_ok && !order.empty() && !use_compact;
+        CompactVecs<T, CM> CV;
+        CompactCoef<CM> CC;
+        TailArgs<T> tail;
+        if (use_compact) { CV = compact_vecs(); CC = compact_prepare(CV); std::memset(&tail, 0, sizeof(tail)); }
+        else tail = use_persist ? two_loop_persist() : two_loop();
+        double gsy[CM] = {0}, gyy[CM] = {0};
+        bool gram_from_trial = false;
         tau = T(1);
         const int xp = xc, xd = (xc + 1) % 3, xb = (xc + 2) % 3;
         const int rp = rc, rn = 1 - rc, zp = zc, zn = 1 - zc;
         int xcur = xd;
         bool have_trial = false, fused_this = false;
-        if (fused_ok) {
+        if (fused_ok && use_compact) {
+            for (int k = 0; k < 10 + 2 * CM; ++k) slot_n[SL_TRIAL + k] = grid;
+            launch(C_FUSED, k_fused_compact<T, CM>, grid, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
+                   gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
+            gather(SL_TRIAL, 10 + 2 * CM, 1u << 9);
+            have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
+            n_grad += 2; n_prox += 1;
+        } else if (fused_ok) {
             launch(C_FUSED, k_fused_sep<T>, grid, tail, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, gamma,
                    X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, (T*)nullptr, (T*)nullptr, n,
                    parts_.p, (int)SL_TRIAL);
@@ -1127,8 +1220,12 @@ template <class T> class Solver final : public SolverBase {
             n_grad += 2; n_prox += 1;
         } else {
             // x_d = x + d ; gradient at x_d ; state.x = x_d
-            launch(C_TWOLOOP, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
-                   parts_.p, 0);
+            if (use_compact)
+                launch(C_TWOLOOP, k_compact_xd<T, CM>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p,
+                       X_[xd].p, n);
+            else
+                launch(C_TWOLOOP, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
+                       parts_.p, 0);
             if (desc.f_kind == BZ_F_STENCIL5 && opt.fuse && !lp_g && !slack && !ctx->multi()) {
                 // stencil fast path: {AL gradient at x_d + FB step} and {AL gradient at z + pair + stop norm}
                 // as two passes; same partial sums as the four generic kernels of the first trial
@@ -1163,9 +1260,17 @@ template <class T> class Solver final : public SolverBase {
                        S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_YS);
                 gather(SL_YS, 3, 4u);
             }
+            if (have_trial && gram_from_trial) {
+                v = collect({SL_FXD, SL_PXD, SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_YS, SL_YTY, SL_STOP,
+                             SL_GU + 0, SL_GU + 1, SL_GU + 2, SL_GU + 3, SL_GU + 4, SL_GU + 5, SL_GU + 6, SL_GU + 7,
+                             SL_GU + 8, SL_GU + 9}, 1u << 9);
+                for (int i = 0; i < CM; ++i) { gsy[i] = v[10 + i]; gyy[i] = v[10 + CM + i]; }
+            } else {
+                v = collect({SL_FXD, SL_PXD, SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_YS, SL_YTY, SL_STOP},
+                            1u << 9);
+                gram_from_trial = false;
+            }
             have_trial = false;
-            v = collect({SL_FXD, SL_PXD, SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_YS, SL_YTY, SL_STOP},
-                        1u << 9);
             f_x = al_value(v[0], v[1]);
             g_z = g_value(v[2]); dot_gr = T(v[3]); ss_res = T(v[4]);
             const T f_z = al_value(v[5], v[6]);
@@ -1195,7 +1300,22 @@ template <class T> class Solver final : public SolverBase {
         // update!(H, x - x_prev, res - res_prev): the pair sits in the spare slot
         const T ys = T(v[7]), yty = T(v[8]);
         last_ys = ys;
-        if (ys > T(0)) lbfgs_insert(ys, yty); else ++n_skips;
+        if (ys > T(0)) {
+            if (compact_ok && !gram_from_trial && !order.empty()) {
+                // the accepted pair is not the one the fused trial measured: its Gram products with the
+                // stored pairs come from their own pass
+                for (int k = 0; k < 2 * CM; ++k) slot_n[SL_GU + k] = grid;
+                launch(C_DOT, k_gram_pair<T, CM>, grid, compact_vecs(), (const T*)Y_[spare].p, n, parts_.p,
+                       (int)SL_GU);
+                gather(SL_GU, 2 * CM, 0u);
+                auto gv = collect({SL_GU + 0, SL_GU + 1, SL_GU + 2, SL_GU + 3, SL_GU + 4, SL_GU + 5, SL_GU + 6,
+                                   SL_GU + 7, SL_GU + 8, SL_GU + 9}, 0u);
+                for (int i = 0; i < CM; ++i) { gsy[i] = gv[i]; gyy[i] = gv[CM + i]; }
+            }
+            lbfgs_insert(ys, yty, gsy, gyy);
+        } else {
+            ++n_skips;
+        }
         stop_norm_ = v[9];
         xc = xcur; rc = rn; zc = zn;
         last_nbt = nbt; last_fused = fused_this;

@@ -26,8 +26,9 @@ class LBFGS:
     """ProximalAlgorithms.LBFGS(memory) — the only `directions` the shipped scripts select
     (demo/rosenbrock.jl:103,275)."""
 
-    def __init__(self, memory=5):
+    def __init__(self, memory=5, compact=False):
         self.memory = int(memory)
+        self.compact = bool(compact)      # same operator, compact (one-reduction-phase) evaluation
 
 
 class NoAcceleration:
@@ -158,6 +159,7 @@ class PANOCplus:
         o.minimum_gamma, o.alpha, o.beta = float(self.minimum_gamma), float(self.alpha), float(self.beta)
         o.max_backtracks, o.lbfgs_memory, o.fuse = int(self.max_backtracks), self.directions.memory, int(bool(self.fuse))
         o.persist = int(bool(self.persist))
+        o.lbfgs_compact = int(bool(getattr(self.directions, "compact", False)))
         return o
 
     def __call__(self, *, f, g, x0):

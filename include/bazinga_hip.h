@@ -150,9 +150,14 @@ typedef struct {
                                 is separable (elementwise f, c = Identity); 0: always
                                 the generic kernel chain.  Results are bit-identical. */
     int32_t persist;         /* 1: run the L-BFGS two-loop as ONE persistent launch with d
-                                register-resident when the vector fits (<= 40 packs/thread)
+                                register-resident when the vector fits (<= 48 packs/thread)
                                 and is long enough; 0: one kernel per two-loop step.
                                 Same arithmetic, different (fixed) summation tree.       */
+    int32_t lbfgs_compact;   /* 1: evaluate the SAME L-BFGS operator in its compact
+                                (Byrd-Nocedal-Schnabel) form: one reduction phase per
+                                application instead of 2M sequential ones (M <= 5).  An
+                                alternate rounding of the two-loop; default 0.            */
+    int32_t reserved;
 } bz_panoc_opts;
 
 void bz_panoc_default_opts(bz_panoc_opts* o);

@@ -35,6 +35,7 @@ Base.@kwdef mutable struct PanocOpts
     tol::Float64 = 1e-8; maxit::Int64 = 1000; freq::Int32 = 10; verbose::Int32 = 0
     minimum_gamma::Float64 = 1e-7; alpha::Float64 = 0.95; beta::Float64 = 0.5
     max_backtracks::Int32 = 20; lbfgs_memory::Int32 = 5; fuse::Int32 = 1; persist::Int32 = 1
+    lbfgs_compact::Int32 = 0; reserved::Int32 = 0
 end
 Base.@kwdef mutable struct PanocStats
     iters::Int64 = 0; f_z::Float64 = 0; g_z::Float64 = 0; al_z::Float64 = 0; gamma::Float64 = 0

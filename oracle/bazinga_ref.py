@@ -632,10 +632,12 @@ def AugLagUpdate(al: AugLagFun, mu, y):                       # :91-101
 #  ProximalAlgorithms.jl restatement (external, unpinned — see module header)
 # ---------------------------------------------------------------------------
 class LBFGS:
-    """``LBFGS(memory)`` direction factory."""
+    """``LBFGS(memory)`` direction factory.  compact=True selects the compact (Byrd-Nocedal-Schnabel)
+    representation of the SAME operator — an alternate evaluation order, see LBFGSCompactOperator."""
 
-    def __init__(self, memory=5):
+    def __init__(self, memory=5, compact=False):
         self.memory = int(memory)
+        self.compact = bool(compact)
 
 
 class NoAcceleration:
@@ -711,6 +713,116 @@ class LBFGSOperator:
                 idx = 1
             beta = _dot(self.y_M[idx - 1], d) / self.ys_M[idx - 1]
             d += (self.alphas[idx - 1] - beta) * self.s_M[idx - 1]
+        return d
+
+
+class LBFGSCompactOperator:
+    """The L-BFGS operator of LBFGSOperator in its compact form (Byrd, Nocedal, Schnabel 1994):
+        H = H0 I + [S, H0 Y] [[R^-T (D + H0 Y'Y) R^-1, -R^-T], [-R^-1, 0]] [S'; H0 Y']
+    with pairs ordered oldest -> newest, R = triu(S'Y), D = diag(S'Y), H0 = ys/yty of the newest pair.
+    Mathematically identical to the two-loop recursion (same pairs, same H0, same insert-iff-<s,y>>0 rule)
+    but ALL 2m inner products with v are independent: one reduction phase per application instead of 2m
+    sequential ones — the form the multi-GPU path uses.  Rounding differs from the
+    two-loop at the 1e-16 level; tests/test_oracle_kat.py shows the two forms agree to that level and then
+    only drift within the restatement's own rounding sensitivity.  The operation order below is the
+    contract the HIP kernels (k_gram_dots, k_fused_sep<COMPACT>) and the host code mirror."""
+
+    def __init__(self, M, x):
+        self.M = M
+        self.S, self.Y = [], []                 # oldest -> newest
+        self.SY = np.zeros((0, 0))              # s_i . y_j  (only i <= j is used)
+        self.YY = np.zeros((0, 0))
+        self.H = x.dtype.type(1)
+        self.dtype = x.dtype
+
+    @property
+    def currmem(self):
+        return len(self.S)
+
+    def reset(self):
+        self.S, self.Y = [], []
+        self.SY = np.zeros((0, 0))
+        self.YY = np.zeros((0, 0))
+        self.H = self.dtype.type(1)
+
+    def update(self, s, y):
+        ys = _dot(s, y)
+        if ys > 0:
+            if len(self.S) == self.M:           # ring full: the oldest pair is overwritten
+                self.S.pop(0); self.Y.pop(0)
+                self.SY = self.SY[1:, 1:]
+                self.YY = self.YY[1:, 1:]
+            m = len(self.S)
+            sy = np.array([float(_dot(self.S[i], y)) for i in range(m)] + [float(ys)])
+            yty = _dot(y, y)
+            yy = np.array([float(_dot(self.Y[i], y)) for i in range(m)] + [float(yty)])
+            SY = np.zeros((m + 1, m + 1)); SY[:m, :m] = self.SY; SY[:, m] = sy
+            YY = np.zeros((m + 1, m + 1)); YY[:m, :m] = self.YY; YY[:, m] = yy; YY[m, :] = yy
+            self.SY, self.YY = SY, YY
+            self.S.append(s.copy()); self.Y.append(y.copy())
+            self.H = ys / yty
+        return ys
+
+    @staticmethod
+    def coefficient_matrices(SY, YY, H0):
+        """M1 = R^-T (D + H0 Y'Y) R^-1 and M2 = R^-1 in float64, explicit loops (fixed order)."""
+        m = SY.shape[0]
+        Ri = np.zeros((m, m))
+        for j in range(m):                      # back-substitution, column j of R^-1
+            Ri[j, j] = 1.0 / SY[j, j]
+            for i in range(j - 1, -1, -1):
+                acc = 0.0
+                for k in range(i + 1, j + 1):
+                    acc += SY[i, k] * Ri[k, j]
+                Ri[i, j] = -acc / SY[i, i]
+        B = np.zeros((m, m))
+        for i in range(m):
+            for j in range(m):
+                B[i, j] = H0 * YY[i, j] + (SY[i, i] if i == j else 0.0)
+        T1 = np.zeros((m, m))                   # T1 = B R^-1
+        for i in range(m):
+            for j in range(m):
+                acc = 0.0
+                for k in range(j + 1):
+                    acc += B[i, k] * Ri[k, j]
+                T1[i, j] = acc
+        M1 = np.zeros((m, m))                   # M1 = R^-T T1
+        for i in range(m):
+            for j in range(m):
+                acc = 0.0
+                for k in range(i + 1):
+                    acc += Ri[k, i] * T1[k, j]
+                M1[i, j] = acc
+        return M1, Ri
+
+    def mul(self, d, v):
+        T = self.dtype.type
+        m = len(self.S)
+        H0 = float(self.H)
+        if m == 0:
+            d[...] = T(H0) * v
+            return d
+        p = [float(_dot(self.S[i], v)) for i in range(m)]
+        w = [float(_dot(self.Y[i], v)) for i in range(m)]
+        M1, M2 = self.coefficient_matrices(self.SY, self.YY, H0)
+        u1, u2 = [0.0] * m, [0.0] * m
+        for i in range(m):
+            a = 0.0
+            for j in range(m):
+                a += M1[i, j] * p[j]
+            b = 0.0
+            for j in range(m):
+                b += M2[j, i] * w[j]
+            u1[i] = a - H0 * b
+            c = 0.0
+            for j in range(m):
+                c += M2[i, j] * p[j]
+            u2[i] = -c
+        d[...] = T(H0) * v
+        for i in range(m):
+            d += T(u1[i]) * self.S[i]
+        for i in range(m):
+            d += T(H0 * u2[i]) * self.Y[i]
         return d
 
 
@@ -819,7 +931,8 @@ class PANOCplusIteration:
         st = PANOCplusState(
             x=x, f_x=f_x, grad_f_x=grad_f_x, gamma=gamma, y=y, z=z, g_z=g_z, res=x - z,
             H=(_NoAccelOperator() if isinstance(self.directions, NoAcceleration)
-               else LBFGSOperator(self.directions.memory, x)),
+               else (LBFGSCompactOperator(self.directions.memory, x) if getattr(self.directions, "compact", False)
+                     else LBFGSOperator(self.directions.memory, x))),
             x_prev=np.empty_like(x), res_prev=np.empty_like(x), d=np.empty_like(x),
             x_d=np.empty_like(x), grad_f_x_d=np.empty_like(x), z_curr=np.empty_like(x),
             grad_f_z=np.empty_like(x),

@@ -16,7 +16,7 @@ N_TOTAL = 800_000
 ITERS = 14
 
 
-def _worker(rank, world, n_total, persist, conn):
+def _worker(rank, world, n_total, persist, conn, compact=False):
     try:
         os.environ["BZ_PERSIST_BLOCKS"] = "96"
         sys.path.insert(0, ROOT)
@@ -32,7 +32,8 @@ def _worker(rank, world, n_total, persist, conn):
                           bz.ClosedSet(bz.IndBox(-1.0, 1.0)), nl, nl, np.float64, ctx)
         y = np.sin(np.arange(lo, hi, dtype=np.float64))
         prob.set_multipliers(np.full(nl, 0.1), y)
-        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist).c_opts(), np.zeros(nl))
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist,
+                                      directions=bz.LBFGS(5, compact=compact)).c_opts(), np.zeros(nl))
         prob.profile_enable(True)
         for _ in range(ITERS):
             prob.panoc_step()
@@ -46,10 +47,10 @@ def _worker(rank, world, n_total, persist, conn):
         conn.send(("error", repr(e)))
 
 
-def _run_sharded(world, persist):
+def _run_sharded(world, persist, compact=False):
     mpc = mp.get_context("spawn")
     pipes = [mpc.Pipe() for _ in range(world)]
-    procs = [mpc.Process(target=_worker, args=(r, world, N_TOTAL, persist, pipes[r][1])) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, N_TOTAL, persist, pipes[r][1], compact)) for r in range(world)]
     for p in procs:
         p.start()
     handles = [pipes[r][0].recv() for r in range(world)]
@@ -67,9 +68,9 @@ def _run_sharded(world, persist):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("persist", [False, True])
-def test_two_ranks_on_one_gpu_match_single_rank(bz, persist):
-    res = _run_sharded(2, persist)
+@pytest.mark.parametrize("persist,compact", [(False, False), (True, False), (False, True)])
+def test_two_ranks_on_one_gpu_match_single_rank(bz, persist, compact):
+    res = _run_sharded(2, persist, compact)
     d = bz.synth.l1_quadratic(N_TOTAL)
     prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
                       bz.ClosedSet(bz.IndBox(-1.0, 1.0)), N_TOTAL, N_TOTAL, np.float64)
@@ -90,5 +91,7 @@ def test_two_ranks_on_one_gpu_match_single_rank(bz, persist):
     assert abs(sa["stop_norm"] - s1["stop_norm"]) <= 1e-8 * max(1.0, s1["stop_norm"])
     if persist:
         assert all(r[6] >= ITERS - 2 for r in res)      # the persistent kernel really ran sharded
+    elif compact:
+        assert all(r[6] == 0 and 2 * ITERS <= r[7] <= 4 * ITERS + 10 for r in res)   # ~2 exchanges per iteration
     else:
         assert all(r[6] == 0 and r[7] > 5 * ITERS for r in res)

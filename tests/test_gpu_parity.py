@@ -753,3 +753,43 @@ def test_randomised_kinds_alps_parity(bz, ref, seed):
         assert np.mean(np.abs(a[0] - o[0]) <= tol * scale) >= 0.999, tag
     else:
         assert np.max(np.abs(a[0] - o[0])) <= tol * scale, tag
+
+
+# ------------------------------------------------------------------ compact L-BFGS (alternate evaluation of the same operator)
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("n", [1000, 300007])
+def test_compact_lbfgs_matches_compact_oracle(bz, ref, n, fuse):
+    """directions = LBFGS(5, compact=True): k_gram_dots + k_fused_compact (or k_compact_xd) against the
+    oracle's LBFGSCompactOperator — the same operation order, so iterates agree within the north-star
+    tolerance — and against the two-loop form, which it equals up to rounding."""
+    d, dev, orc = make_cfg2(bz, ref, n)
+    rng = np.random.default_rng(5)
+    mu, y, x0 = np.full(n, 0.1), rng.standard_normal(n), np.zeros(n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse, directions=bz.LBFGS(5, compact=True)).c_opts(), x0)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
+    it = ref.PANOCplusIteration(al, ref.NonsmoothCostFun(orc[1]), x0, directions=ref.LBFGS(5, compact=True))
+    al2 = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
+    it2 = ref.PANOCplusIteration(al2, ref.NonsmoothCostFun(orc[1]), x0)
+    st, st2 = it.init(), it2.init()
+    for k in range(30):
+        xd, zd = prob.panoc_vector("x"), prob.panoc_vector("z")
+        assert rel(xd, st.x) <= RTOL_ITER and rel(zd, st.z) <= RTOL_ITER, f"compact oracle mismatch at k={k + 1}"
+        assert rel(zd, st2.z) <= 1e-9, f"two-loop form mismatch at k={k + 1}"
+        sc = prob.panoc_scalars()
+        assert sc["lbfgs_mem"] == st.H.currmem
+        prob.panoc_step()
+        st, st2 = it.step(st), it2.step(st2)
+    prob.close()
+
+
+def test_compact_lbfgs_alps(bz, ref):
+    n = 4000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    a = bz.alps(*dev, x0, y0, subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(5, compact=True), **kw), resident=True)
+    o = ref.alps(*orc, x0, y0)
+    assert a[5] == o[5] == "first_order" and a[2] == o[2]
+    assert abs(a[3] - o[3]) <= max(3, 0.05 * o[3])
+    assert rel(a[0], o[0]) <= 1e-8

@@ -1512,41 +1512,50 @@ k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* 
     block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
 }
 
-// fold 2*MM scalar sources at once: wave w folds sources w, w+4, ... (fixed order), results in sh_out
+// fold 2*MM scalar sources at once: wave w folds sources w, w+4, ... (fixed order), results in sh_out.
+// All indices into the kernel-argument arrays are compile-time (a run-time index would make the compiler
+// copy the whole argument block to scratch memory in every thread).
 template <int MM>
-__device__ __forceinline__ void fold_many(const ScalarSrc* srcs, int m, double* sh_out) {
+__device__ __forceinline__ void fold_many(const ScalarSrc (&srcs)[2 * MM], int m, double* sh_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < 2 * MM; k += WAVES) {
-        const int idx = k < MM ? k : k - MM;
-        double v = 0.0;
-        if (idx < m) {
-            const ScalarSrc s = srcs[k];
-            for (int i = lane; i < s.count; i += 64) v += s.p[(size_t)i * s.stride];
-            v = wave_sum(v);
+#pragma unroll
+    for (int k = 0; k < 2 * MM; ++k) {
+        if ((k % WAVES) == wave) {                   // wave-uniform
+            const int idx = k < MM ? k : k - MM;
+            double v = 0.0;
+            if (idx < m) {
+                const double* p = srcs[k].p;
+                const int count = srcs[k].count, stride = srcs[k].stride;
+                for (int i = lane; i < count; i += 64) v += p[(size_t)i * stride];
+                v = wave_sum(v);
+            }
+            if (lane == 0) sh_out[k] = v;
         }
-        if (lane == 0) sh_out[k] = v;
     }
     __syncthreads();
 }
 
-// coefficients of the compact form for this application: every block computes the same bits
+// coefficients of the compact form for this application: every thread computes the same bits
+//   u1 = M1 p - H0 M2' w ; u2h = H0 * (-(M2 p))      (rows/columns beyond m are zero)
 template <class T, int MM>
 __device__ __forceinline__ void compact_coefs(const CompactCoef<MM>& C, int m, T (&u1)[MM], T (&u2h)[MM]) {
     __shared__ double pw[2 * MM];
-    __shared__ double us[2 * MM];
     fold_many<MM>(C.psrc, m, pw);
-    if (threadIdx.x < MM) {
-        const int i = threadIdx.x;
-        double a = 0.0, b = 0.0, c = 0.0;
-        for (int j = 0; j < m; ++j) a += C.M1[i * MM + j] * pw[j];
-        for (int j = 0; j < m; ++j) b += C.M2[j * MM + i] * pw[MM + j];
-        for (int j = 0; j < m; ++j) c += C.M2[i * MM + j] * pw[j];
-        us[i] = (i < m) ? a - C.H0 * b : 0.0;
-        us[MM + i] = (i < m) ? C.H0 * (-c) : 0.0;          // H0 * u2_i
-    }
-    __syncthreads();
+    double p[MM], w[MM];
 #pragma unroll
-    for (int i = 0; i < MM; ++i) { u1[i] = (T)us[i]; u2h[i] = (T)us[MM + i]; }
+    for (int j = 0; j < MM; ++j) { p[j] = pw[j]; w[j] = pw[MM + j]; }
+#pragma unroll
+    for (int i = 0; i < MM; ++i) {
+        double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < MM; ++j) a += C.M1[i * MM + j] * p[j];
+#pragma unroll
+        for (int j = 0; j < MM; ++j) b += C.M2[j * MM + i] * w[j];
+#pragma unroll
+        for (int j = 0; j < MM; ++j) c += C.M2[i * MM + j] * p[j];
+        u1[i] = (T)(a - C.H0 * b);
+        u2h[i] = (T)(C.H0 * (-c));
+    }
 }
 
 // d for one pack:  d = H0 v + sum u1_i s_i + sum (H0 u2_i) y_i ,  v = -res

@@ -8,13 +8,15 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 fuse = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 persist = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+compact = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 d = bz.synth.l1_quadratic(n)
 prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
                   bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), n, n, np.float64)
 print(prob.ctx.info())
 mu = np.full(n, 0.1); y = np.zeros(n)
 prob.set_multipliers(mu, y)
-opts = bz.PANOCplus(tol=0.0, maxit=10**9, minimum_gamma=np.finfo(float).eps, fuse=bool(fuse), persist=bool(persist)).c_opts()
+opts = bz.PANOCplus(tol=0.0, maxit=10**9, minimum_gamma=np.finfo(float).eps, fuse=bool(fuse), persist=bool(persist),
+                    directions=bz.LBFGS(5, compact=bool(compact))).c_opts()
 prob.panoc_begin(opts, np.zeros(n))
 for _ in range(20):
     prob.panoc_step()
@@ -24,7 +26,7 @@ for _ in range(steps):
 t1 = time.perf_counter()
 sc = prob.panoc_scalars(); st = prob.panoc_stats()
 its = steps / (t1 - t0)
-print(f"n={n} fuse={fuse} persist={persist}: {its:.1f} it/s  ({1e6/its:.1f} us/it)  model 520n B/it -> {520*n*its/1e12:.3f} TB/s = {520*n*its/8e12:.3f} of 8 TB/s")
+print(f"n={n} fuse={fuse} persist={persist} compact={compact}: {its:.1f} it/s  ({1e6/its:.1f} us/it)  model 520n B/it -> {520*n*its/1e12:.3f} TB/s = {520*n*its/8e12:.3f} of 8 TB/s")
 print("scalars", sc)
 print("stats fused", st.n_fused_iters, "grad", st.n_grad, "prox", st.n_prox, "bt", st.n_backtracks, "halv", st.n_gamma_halvings, "skips", st.n_lbfgs_skips)
 prob.profile_enable(True); prob.profile_reset()

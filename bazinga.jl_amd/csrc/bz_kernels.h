@@ -1517,20 +1517,33 @@ k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* 
 // copy the whole argument block to scratch memory in every thread).
 template <int MM>
 __device__ __forceinline__ void fold_many(const ScalarSrc (&srcs)[2 * MM], int m, double* sh_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every thread strides over the partials of ALL sources at once: 2*MM independent loads per step, so
+    // the whole fold costs about one memory latency instead of one per partial
+    __shared__ double shw[WAVES][2 * MM];
+    double acc[2 * MM];
+    int maxcount = 0;
 #pragma unroll
     for (int k = 0; k < 2 * MM; ++k) {
-        if ((k % WAVES) == wave) {                   // wave-uniform
+        acc[k] = 0.0;
+        const int idx = k < MM ? k : k - MM;
+        if (idx < m && srcs[k].count > maxcount) maxcount = srcs[k].count;
+    }
+    for (int i = threadIdx.x; i < maxcount; i += BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 2 * MM; ++k) {
             const int idx = k < MM ? k : k - MM;
-            double v = 0.0;
-            if (idx < m) {
-                const double* p = srcs[k].p;
-                const int count = srcs[k].count, stride = srcs[k].stride;
-                for (int i = lane; i < count; i += 64) v += p[(size_t)i * stride];
-                v = wave_sum(v);
-            }
-            if (lane == 0) sh_out[k] = v;
+            if (idx < m && i < srcs[k].count) acc[k] += srcs[k].p[(size_t)i * srcs[k].stride];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * MM; ++k) {
+        const double v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * MM) {
+        const int k = threadIdx.x;
+        sh_out[k] = (shw[0][k] + shw[1][k]) + (shw[2][k] + shw[3][k]);
     }
     __syncthreads();
 }

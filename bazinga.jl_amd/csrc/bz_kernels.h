@@ -1517,27 +1517,23 @@ k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* 
 // copy the whole argument block to scratch memory in every thread).
 template <int MM>
 __device__ __forceinline__ void fold_many(const ScalarSrc (&srcs)[2 * MM], int m, double* sh_out) {
-    // every thread strides over the partials of ALL sources at once: 2*MM independent loads per step, so
-    // the whole fold costs about one memory latency instead of one per partial
+    // every thread strides over the partials of ALL sources at once: 2*MM independent, unconditional loads
+    // per step (the host points unused sources at valid memory and gives all sources the same count and
+    // stride), so the whole fold costs about one memory latency instead of one per partial
     __shared__ double shw[WAVES][2 * MM];
     double acc[2 * MM];
-    int maxcount = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * MM; ++k) acc[k] = 0.0;
+    const int count = srcs[0].count, stride = srcs[0].stride;
+    for (int i = threadIdx.x; i < count; i += BLOCK) {
+        const size_t off = (size_t)i * stride;
+#pragma unroll
+        for (int k = 0; k < 2 * MM; ++k) acc[k] += srcs[k].p[off];
+    }
 #pragma unroll
     for (int k = 0; k < 2 * MM; ++k) {
-        acc[k] = 0.0;
         const int idx = k < MM ? k : k - MM;
-        if (idx < m && srcs[k].count > maxcount) maxcount = srcs[k].count;
-    }
-    for (int i = threadIdx.x; i < maxcount; i += BLOCK) {
-#pragma unroll
-        for (int k = 0; k < 2 * MM; ++k) {
-            const int idx = k < MM ? k : k - MM;
-            if (idx < m && i < srcs[k].count) acc[k] += srcs[k].p[(size_t)i * srcs[k].stride];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 2 * MM; ++k) {
-        const double v = wave_sum(acc[k]);
+        const double v = wave_sum(idx < m ? acc[k] : 0.0);
         if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();

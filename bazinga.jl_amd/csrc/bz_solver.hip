@@ -960,7 +960,7 @@ template <class T> class Solver final : public SolverBase {
         std::memset(&C, 0, sizeof(C));
         C.H0 = (double)H;
         compact_matrices(C.H0, C.M1, C.M2);
-        for (int k = 0; k < 2 * CM; ++k) C.psrc[k] = src(SL_GP + k);
+        for (int k = 0; k < 2 * CM; ++k) C.psrc[k] = src(SL_GP + k);   // all valid, same count/stride (fold_many)
         return C;
     }
 

@@ -1205,8 +1205,11 @@ template <class T> class Solver final : public SolverBase {
         int xcur = xd;
         bool have_trial = false, fused_this = false;
         if (fused_ok && use_compact) {
-            for (int k = 0; k < 10 + 2 * CM; ++k) slot_n[SL_TRIAL + k] = grid;
-            launch(C_FUSED, k_fused_compact<T, CM>, grid, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
+            // 176 VGPRs -> two 256-thread blocks per CU: one resident round of blocks (each block pays the
+            // coefficient prologue and a 20-slot reduction epilogue once)
+            const int gfc = std::min(grid, 2 * std::max(1, num_cus));
+            for (int k = 0; k < 10 + 2 * CM; ++k) slot_n[SL_TRIAL + k] = gfc;
+            launch(C_FUSED, k_fused_compact<T, CM>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
                    gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
             gather(SL_TRIAL, 10 + 2 * CM, 1u << 9);
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;

@@ -1152,6 +1152,7 @@ template <class T> class Solver final : public SolverBase {
         }
         if (gamma < min_gamma)
             std::fprintf(stderr, "Warning: stepsize `gamma` became too small (%g)\n", (double)gamma);
+        for (int k = 0; k < 3; ++k) slot_n[SL_YS + k] = grid;
         launch(C_UPDATE, k_update<T>, grid, (const T*)x, (const T*)nullptr, (const T*)RES_[rc].p,
                (const T*)nullptr, (const T*)GX_.p, (const T*)GZ_.p, gamma, (T*)nullptr, (T*)nullptr, n,
                parts_.p, (int)SL_YS);
@@ -1215,6 +1216,7 @@ template <class T> class Solver final : public SolverBase {
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
             n_grad += 2; n_prox += 1;
         } else if (fused_ok) {
+            for (int k = 0; k < 10; ++k) slot_n[SL_TRIAL + k] = grid;
             launch(C_FUSED, k_fused_sep<T>, grid, tail, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, gamma,
                    X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, (T*)nullptr, (T*)nullptr, n,
                    parts_.p, (int)SL_TRIAL);
@@ -1258,6 +1260,7 @@ template <class T> class Solver final : public SolverBase {
                 gather(SL_GSUM, 3, 0u);
                 ++n_prox;
                 algrad(Z_[zn].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
+                for (int kk = 0; kk < 3; ++kk) slot_n[SL_YS + kk] = grid;
                 launch(C_UPDATE, k_update<T>, grid, (const T*)X_[xcur].p, (const T*)X_[xp].p,
                        (const T*)RES_[rn].p, (const T*)RES_[rp].p, (const T*)GX_.p, (const T*)GZ_.p, gamma,
                        S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_YS);

@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-states", type=int, default=31)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--compact", action="store_true", help="compact L-BFGS form also at N = 1")
+    ap.add_argument("--two-loop", action="store_true", help="N > 1: keep the two-loop form (11 exchanges per iteration)")
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: keep the RCCL all-gather for the scalar exchange")
     args = ap.parse_args()
 
@@ -167,8 +169,12 @@ def main():
     lo_i, hi_i = bz.shard_bounds(n, rank, world)
     nl = hi_i - lo_i
     d = bz.synth.l1_quadratic(nl, start=lo_i)
+    # N > 1: the L-BFGS operator is evaluated in its compact form (one reduction phase per application
+    # instead of 2M sequential ones: 2 cross-GPU exchanges per iteration instead of 11).  Same operator,
+    # alternate rounding (oracle: LBFGSCompactOperator; tests: test_compact_lbfgs_*).
+    compact = (world > 1 and not args.two_loop) or args.compact
     popts = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),
-                         fuse=not args.no_fuse).c_opts()
+                         fuse=not args.no_fuse, directions=bz.LBFGS(M_LBFGS, compact=compact)).c_opts()
 
     def make_problem(c):
         p = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
@@ -239,7 +245,7 @@ def main():
     # HIP events bound to each dispatch on the library's own stream (hipExtLaunchKernelGGL start/stop
     # events).  Warm-up: every kernel category is timed, to find the dominant kernel and fill the
     # per-kernel table; timed region: only the dominant kernel carries events (one launch per iteration).
-    ALG = ("k_twoloop_persist", "k_axpy_dot", "k_fused_sep")
+    ALG = ("k_twoloop_persist", "k_axpy_dot", "k_fused_sep", "k_dot")
     prob.profile_reset()
     prob.profile_enable(True)
     for _ in range(args.warmup):
@@ -279,7 +285,12 @@ def main():
         #   k_fused_sep       : last axpy + x_d (4) + 2 AL gradients (2*6) + FB step (4) + update/stop (8)
         alg_passes = {"k_twoloop_persist": (8 * m + 1) - 4,
                       "k_axpy_dot": (4.0 * (2 * m - 2) + 3.0) / (2 * m - 1) if m >= 1 else 0.0,
-                      "k_fused_sep": 4 + 12 + 4 + 8}
+                      "k_fused_sep": 4 + 12 + 4 + 8, "k_dot": 2}
+        if compact:
+            # compact form: k_gram_dots reads res + S[m] + Y[m]; k_fused_compact reads res, S[m], Y[m], x, q, b,
+            # mu, mu*y and writes x_d, z, res, s, y — the model's two-loop share (8m+1 passes) is split between them
+            alg_passes["k_dot"] = 2 * m + 1
+            alg_passes["k_fused_sep"] = (8 * m + 1) - (2 * m + 1) + 12 + 4 + 8
         prof = prof_all[dom]
         launches_per_it = (st1.n_fused_iters - st0.n_fused_iters) / max(1, args.steps) if dom != "k_axpy_dot" else 9.0
         bytes_per_launch = alg_passes[dom] * w * nl
@@ -305,10 +316,13 @@ def main():
                        "parallelism": "single GPU" if world == 1 else
                        f"x sharded over {world} GPUs, scalars exchanged by " +
                        ("peer-to-peer mailboxes over xGMI" if transport == "p2p" else "RCCL all-gather"),
-                       "scalar_transport": transport, "p2p_note": p2p_note},
+                       "scalar_transport": transport, "p2p_note": p2p_note,
+                       "lbfgs_form": "compact (1 reduction phase per application)" if compact
+                       else "two-loop (persistent kernel, 2M-1 grid phases)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "bz::%s<double>" % dom, "launches_per_iteration": round(launches_per_it, 2),
+                         "kernel": "bz::%s<double>" % ({"k_fused_sep": "k_fused_compact", "k_dot": "k_gram_dots"}.get(dom, dom)
+                                                         if compact else dom), "launches_per_iteration": round(launches_per_it, 2),
                          "avg_launch_us": round(avg_s * 1e6, 3), "timed_launches": prof["launches"],
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "algorithmic_passes_per_launch": round(alg_passes[dom], 3)},

@@ -80,6 +80,7 @@ SIGNATURES = {
     "bz_comm_unique_id": (C.c_int, [_vp]),
     "bz_ctx_create": (C.c_int, [_P(CtxOpts), _P(_vp)]),
     "bz_ctx_destroy": (None, [_vp]),
+    "bz_ctx_synchronize": (C.c_int, [_vp]),
     "bz_ctx_p2p_export": (C.c_int, [_vp, _vp]),
     "bz_ctx_p2p_connect": (C.c_int, [_vp, _vp, _P(C.c_int32)]),
     "bz_last_error": (C.c_char_p, []),

@@ -92,6 +92,15 @@ int bz_ctx_p2p_connect(bz_ctx* ctx, const void* handles, const int32_t* devices)
     return guard([&] { need(ctx, "ctx"); need(handles, "handles"); bz::p2p_connect(&ctx->c, handles, devices); });
 }
 
+int bz_ctx_synchronize(bz_ctx* ctx) {
+    return guard([&] {
+        need(ctx, "ctx");
+        BZ_HIP(hipSetDevice(ctx->c.device));
+        BZ_HIP(hipStreamSynchronize(ctx->c.stream));
+        BZ_HIP(hipDeviceSynchronize());
+    });
+}
+
 int bz_device_info(bz_ctx* ctx, char* name256, int32_t* cus, int64_t* mem_bytes) {
     return guard([&] {
         need(ctx, "ctx");

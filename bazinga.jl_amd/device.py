@@ -37,6 +37,10 @@ class Context:
         L.check(L.load().bz_comm_unique_id(buf))
         return buf.raw
 
+    def synchronize(self):
+        """Drain the solver stream and the device (hipDeviceSynchronize)."""
+        L.check(L.load().bz_ctx_synchronize(self._h))
+
     def p2p_export(self) -> bytes:
         """This rank's mailbox IPC handle (64 bytes); all-gather them, then p2p_connect."""
         buf = C.create_string_buffer(64)

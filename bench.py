@@ -55,9 +55,147 @@ def cpu_baseline(n, states):
             "host_cpus": os.cpu_count()}
 
 
+class SocketGroup:
+    """Minimal process group over TCP (star through rank 0) for the launcher-side plumbing of N > 1:
+    all-gather of small byte strings, barrier, max/min reductions.  torch.distributed would do, but
+    importing torch makes libbazinga_hip bind to torch's bundled ROCm 7.0 HIP runtime instead of the
+    system's 7.2 (measured: +20 us per iteration of launch overhead); the data path never uses this."""
+    MAGIC = b"BZRV1"
+
+    def __init__(self, rank, world, addr, port, timeout=120.0):
+        import socket
+        import struct
+        self.rank, self.world, self._struct = rank, world, struct
+        self.peers = []
+        if rank == 0:
+            srv = None
+            for off in range(1, 40):
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, port + off))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError("no free rendezvous port")
+            srv.listen(world)
+            srv.settimeout(timeout)
+            slots = [None] * world
+            while sum(c is not None for c in slots[1:]) < world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                hello = self._recvn(c, len(self.MAGIC) + 4)
+                if hello[:len(self.MAGIC)] != self.MAGIC:
+                    c.close()
+                    continue
+                r = struct.unpack("<i", hello[len(self.MAGIC):])[0]
+                c.sendall(b"BZOK")
+                slots[r] = c
+            self.peers = slots
+            srv.close()
+        else:
+            deadline = time.time() + timeout
+            sock = None
+            while sock is None and time.time() < deadline:
+                for off in range(1, 40):
+                    try:
+                        c = socket.create_connection((addr, port + off), timeout=2.0)
+                        c.settimeout(5.0)
+                        c.sendall(self.MAGIC + struct.pack("<i", rank))
+                        if self._recvn(c, 4) == b"BZOK":
+                            c.settimeout(timeout)
+                            sock = c
+                            break
+                        c.close()
+                    except OSError:
+                        continue
+                if sock is None:
+                    time.sleep(0.2)
+            if sock is None:
+                raise RuntimeError("could not reach rank 0")
+            self.sock = sock
+
+    @staticmethod
+    def _recvn(c, n):
+        buf = b""
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise RuntimeError("peer closed the rendezvous connection")
+            buf += chunk
+        return buf
+
+    def _send(self, c, b):
+        c.sendall(self._struct.pack("<i", len(b)) + b)
+
+    def _recv(self, c):
+        n = self._struct.unpack("<i", self._recvn(c, 4))[0]
+        return self._recvn(c, n)
+
+    def allgather(self, b: bytes):
+        if self.rank == 0:
+            parts = [b] + [self._recv(self.peers[r]) for r in range(1, self.world)]
+            blob = b"".join(self._struct.pack("<i", len(x)) + x for x in parts)
+            for r in range(1, self.world):
+                self._send(self.peers[r], blob)
+            return parts
+        self._send(self.sock, b)
+        blob = self._recv(self.sock)
+        out, o = [], 0
+        for _ in range(self.world):
+            n = self._struct.unpack("<i", blob[o:o + 4])[0]
+            out.append(blob[o + 4:o + 4 + n])
+            o += 4 + n
+        return out
+
+    def barrier(self):
+        self.allgather(b"")
+
+    def reduce(self, x: float, op):
+        vals = [self._struct.unpack("<d", v)[0] for v in self.allgather(self._struct.pack("<d", float(x)))]
+        return op(vals)
+
+    def close(self):
+        for c in self.peers[1:] if self.rank == 0 else [self.sock]:
+            try:
+                c.close()
+            except OSError:
+                pass
+
+
+class TorchGroup:
+    """Same interface over torch.distributed (fallback if the TCP rendezvous cannot be set up)."""
+
+    def __init__(self, rank, world, local_rank):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def allgather(self, b: bytes):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, b)
+        return out
+
+    def barrier(self):
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, x, op):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, float(x))
+        return op(out)
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
 def side_workload(args):
     """cfg 3 / cfg 4 (single GPU): the other BASELINE configs, same JSON shape; not the headline."""
-    import torch
     import bazinga_jl_amd as bz
     eps64, eps32 = float(np.finfo(np.float64).eps), float(np.finfo(np.float32).eps)
     if args.workload == "cfg3":
@@ -87,11 +225,11 @@ def side_workload(args):
         prob.panoc_step()
     prob.profile_reset()
     prob.profile_enable(True)
-    torch.cuda.synchronize()
+    prob.ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         prob.panoc_step()
-    torch.cuda.synchronize()
+    prob.ctx.synchronize()
     elapsed = time.perf_counter() - t0
     prob.profile_enable(False)
     prof_all = prob.profile()
@@ -138,7 +276,6 @@ def main():
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: keep the RCCL all-gather for the scalar exchange")
     args = ap.parse_args()
 
-    import torch
     import bazinga_jl_amd as bz
 
     n = int(args.n)
@@ -152,17 +289,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with that many ranks "
                          f"(WORLD_SIZE={world})")
-    dist = None
+    grp = None
     comm_id = None
     if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt = torch.frombuffer(bytearray(bz.Context.unique_id()), dtype=torch.uint8).cuda()
-        dist.broadcast(idt, 0)
-        comm_id = bytes(idt.cpu().numpy().tobytes())
+        try:
+            grp = SocketGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                              int(os.environ.get("MASTER_PORT", "29500")))
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] TCP rendezvous failed ({e!r}); using torch.distributed", file=sys.stderr, flush=True)
+            grp = TorchGroup(rank, world, local_rank)
+        ids = grp.allgather(bz.Context.unique_id() if rank == 0 else b"")
+        comm_id = ids[0]
     dev = local_rank if world > 1 else 0
     ctx = bz.Context(device=dev, rank=rank, nranks=world, comm_id=comm_id)
 
@@ -190,25 +327,20 @@ def main():
     p2p_note = None
     if world > 1 and not args.no_p2p:
         def agree(flag):
-            t = torch.tensor([flag], dtype=torch.int32, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return int(t.item()) == 1
+            return grp.reduce(flag, min) >= 1
 
         ok, ctx2 = 1, None
         try:                                    # stage 1: map everybody's mailbox
             ctx2 = bz.Context(device=dev, rank=rank, nranks=world, comm_id=None)
-            h = torch.frombuffer(bytearray(ctx2.p2p_export()), dtype=torch.uint8).cuda()
+            h = ctx2.p2p_export()
         except Exception as e:      # noqa: BLE001
             ok, p2p_note = 0, f"p2p export failed: {e!r}"[:300]
-            h = torch.zeros(64, dtype=torch.uint8, device="cuda")
-        hs = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(world)]
-        dist.all_gather(hs, h)
-        dv = torch.tensor([dev], dtype=torch.int32, device="cuda")
-        dvs = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(world)]
-        dist.all_gather(dvs, dv)
+            h = b"\0" * 64
+        hs = grp.allgather(h)
+        dvs = [int(v) for v in grp.allgather(str(dev).encode())]
         if agree(ok):
             try:
-                ctx2.p2p_connect([bytes(t.cpu().numpy().tobytes()) for t in hs], [int(t.item()) for t in dvs])
+                ctx2.p2p_connect(hs, dvs)
             except Exception as e:      # noqa: BLE001
                 ok, p2p_note = 0, f"p2p connect failed: {e!r}"[:300]
         else:
@@ -238,9 +370,10 @@ def main():
     del d
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        ctx.synchronize()
+        if grp is not None:
+            grp.barrier()
+        ctx.synchronize()
 
     # HIP events bound to each dispatch on the library's own stream (hipExtLaunchKernelGGL start/stop
     # events).  Warm-up: every kernel category is timed, to find the dominant kernel and fill the
@@ -263,10 +396,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prob.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if grp is not None:
+        elapsed = grp.reduce(elapsed, max)
     st1 = prob.panoc_stats()
     sc = prob.panoc_scalars()
     prof_all = prob.profile()
@@ -344,9 +475,9 @@ def main():
         print(json.dumps(out), flush=True)
     prob.close()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if grp is not None:
+        grp.barrier()
+        grp.close()
 
 
 if __name__ == "__main__":

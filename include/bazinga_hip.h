@@ -88,6 +88,7 @@ typedef struct {
 int  bz_comm_unique_id(void* id128);                 /* fills 128 bytes (RCCL id)     */
 int  bz_ctx_create(const bz_ctx_opts* opts, bz_ctx** out);
 void bz_ctx_destroy(bz_ctx* ctx);
+int  bz_ctx_synchronize(bz_ctx* ctx);                /* drains the solver stream and the device */
 /* Peer-to-peer scalar mailboxes (single node, optional; replaces the RCCL all-gather and lets the
  * persistent two-loop kernel run sharded): every rank exports the 64-byte HIP IPC handle of its
  * mailbox, the launcher all-gathers the handles and the device ordinals, every rank connects.      */

@@ -380,14 +380,14 @@ def main():
     # per-kernel table; timed region: only the dominant kernel carries events (one launch per iteration).
     ALG = ("k_twoloop_persist", "k_axpy_dot", "k_fused_sep", "k_dot")
     prob.profile_reset()
-    prob.profile_enable(True)
+    prob.profile_enable(os.environ.get("BZ_BENCH_WARMPROF", "1") == "1")
     for _ in range(args.warmup):
         prob.panoc_step()
     prof_warm = prob.profile()
     cands = {k: v for k, v in prof_warm.items() if k in ALG and v["launches"]}
     dom = max(cands, key=lambda k: cands[k]["total_ms"]) if cands else "k_axpy_dot"
     prob.profile_reset()
-    prob.profile_enable(1 << bz._lib.KERNEL_CATEGORIES.index(dom), period=8)
+    prob.profile_enable(1 << bz._lib.KERNEL_CATEGORIES.index(dom), period=int(os.environ.get("BZ_BENCH_PERIOD", "8")))
     st0 = prob.panoc_stats()
     barrier()
     t0 = time.perf_counter()

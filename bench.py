@@ -456,7 +456,11 @@ def main():
                                                          if compact else dom), "launches_per_iteration": round(launches_per_it, 2),
                          "avg_launch_us": round(avg_s * 1e6, 3), "timed_launches": prof["launches"],
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "algorithmic_passes_per_launch": round(alg_passes[dom], 3)},
+                         "algorithmic_passes_per_launch": round(alg_passes[dom], 3),
+                         # what the memory system actually sustained: PMC bytes / measured duration.  frac above
+                         # can exceed 1 because the kernel moves fewer bytes than the reference's dataflow needs.
+                         "traffic_rate": round(traffic / avg_s / 1e9, 1) if traffic and avg_s > 0 else None,
+                         "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_s > 0 else None},
             "kernels_warmup": {k: {"launches_per_iteration": round(v["launches"] / max(1, args.warmup), 2),
                                    "avg_us": round(1e3 * v["total_ms"] / v["launches"], 2)}
                                for k, v in prof_warm.items() if v["launches"]},

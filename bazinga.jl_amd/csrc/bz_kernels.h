@@ -98,6 +98,31 @@ __device__ __forceinline__ double fold_src(ScalarSrc s, bool is_max, double* sh 
     return t;
 }
 
+// the same fold done by ONE wave, bit for bit: lane l plays threads l, l+64, l+128, l+192 of fold_src
+// (unit stride).  Lets a block fold several scalars at once, one per wave.  Every lane gets the result.
+__device__ __forceinline__ double fold_wave(const double* p, int count, bool is_max) {
+    const int l = threadIdx.x & 63;
+    // all loads first (one memory latency instead of count/256 of them); missing entries read as +0.0,
+    // which is neutral for both folds (the accumulators start at +0.0 and never become -0.0)
+    double v[PSTRIDE / BLOCK][WAVES];
+#pragma unroll
+    for (int k = 0; k < PSTRIDE / BLOCK; ++k)
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const int i = k * BLOCK + w * 64 + l;
+            v[k][w] = i < count ? p[i] : 0.0;
+        }
+    double a[WAVES] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < PSTRIDE / BLOCK; ++k)
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) a[w] = is_max ? nanmax(a[w], v[k][w]) : a[w] + v[k][w];
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) a[w] = is_max ? wave_max(a[w]) : wave_sum(a[w]);
+    const double t = is_max ? nanmax(nanmax(a[0], a[1]), nanmax(a[2], a[3])) : ((a[0] + a[1]) + (a[2] + a[3]));
+    return __shfl(t, 0, 64);
+}
+
 // block-reduce K accumulators and write one partial per slot.
 // maxmask bit k set -> slot k is a max.
 template <int K>
@@ -806,8 +831,7 @@ k_gemv_t_finish(const T* __restrict__ part, int nchunks, int64_t pstride, const 
 struct P2PWords {            // device view of bz::P2PMailbox (bz_solver.h); same layout
     double pval[2][8];
     unsigned long long pflag[2][8];
-    double xval[2][8][32];
-    unsigned long long xflag[2][8];
+    unsigned long long xll[2][8][32][2];   // pack exchanges: {low half | tag << 32}, {high half | tag << 32}
 };
 __device__ __forceinline__ void sys_store(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -825,9 +849,20 @@ constexpr unsigned XSPIN_LIMIT = 20000000u;
 
 // fold this rank's block partials of slots [first, first+cnt), exchange the pack with all ranks and
 // leave every rank's pack in recv[r*cnt + i] (the layout ScalarSrc{recv, nranks, cnt} expects)
+constexpr int XBLOCK = 1024;              // 16 waves: up to 16 scalars folded at once
+struct SlotCounts {                       // valid block partials per slot, 16 bits each (<= PSTRIDE = 2048)
+    unsigned long long w[8];
+    __host__ __device__ void set(int i, int c) { w[i >> 2] |= (unsigned long long)(c & 0xFFFF) << ((i & 3) * 16); }
+    __device__ __forceinline__ int get(int i) const {
+        unsigned long long v = w[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) if ((i >> 2) == k) v = w[k];      // compile-time indices: stays in SGPRs
+        return (int)((v >> ((i & 3) * 16)) & 0xFFFFull);
+    }
+};
 struct XchgArgs {
     const double* parts;
-    int counts[32];          // valid block partials per slot
+    SlotCounts counts;
     int first, cnt;
     unsigned maxmask;
     int rank, nranks;
@@ -837,36 +872,47 @@ struct XchgArgs {
     P2PWords* mbox_peer[8];
     int* timeout;
 };
-static __global__ void __launch_bounds__(BLOCK) k_exchange(XchgArgs a) {
-    __shared__ double sh[WAVES];
+// The pack travels in "LL" form: every 8-byte word carries half a value and a 32-bit tag of the
+// exchange's sequence number, so a word is valid exactly when its tag matches — no separate flag, no
+// fence between data and flag, one store latency + one load latency per exchange.  8-byte stores are
+// single-copy atomic, and each half is checked against its own tag, so a torn pair cannot be taken.
+__device__ __forceinline__ unsigned ll_tag(unsigned long long seq) { return (unsigned)(seq & 0x7FFFFFFFull) + 1u; }
+static __global__ void __launch_bounds__(XBLOCK) k_exchange(XchgArgs a) {
     __shared__ double vals[32];
-    for (int i = 0; i < a.cnt; ++i) {
-        ScalarSrc s{a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts[i], 1};
-        const double t = fold_src(s, (a.maxmask >> i) & 1u, sh);
-        if (threadIdx.x == 0) vals[i] = t;
+    const int tid = threadIdx.x;
+    for (int i = tid >> 6; i < a.cnt; i += XBLOCK / 64) {
+        const double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
+        if ((tid & 63) == 0) vals[i] = t;
     }
     __syncthreads();
     const int par = (int)(a.seq & 1ull);
-    const int tid = threadIdx.x;
+    const unsigned long long tag = (unsigned long long)ll_tag(a.seq) << 32;
     if (tid < a.nranks * a.cnt) {
         const int r = tid / a.cnt, i = tid % a.cnt;
-        sys_store(&a.mbox_peer[r]->xval[par][a.rank][i], vals[i]);
-    }
-    __threadfence_system();          // every storing lane: data before flag
-    __syncthreads();
-    if (tid < a.nranks) sys_store(&a.mbox_peer[tid]->xflag[par][a.rank], a.seq);
-    if (tid < a.nranks) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[i]);
+        unsigned long long* dst = a.mbox_peer[r]->xll[par][a.rank][i];
+        sys_store(dst + 0, tag | (bits & 0xFFFFFFFFull));
+        sys_store(dst + 1, tag | (bits >> 32));
+        const unsigned long long* src = a.mbox_local->xll[par][r][i];
+        unsigned long long w0, w1;
         unsigned spins = 0;
-        while (sys_load(&a.mbox_local->xflag[par][tid]) < a.seq) {
-            __builtin_amdgcn_s_sleep(2);
+        for (;;) {
+            w0 = sys_load(src + 0);
+            w1 = sys_load(src + 1);
+            if ((w0 >> 32 << 32) == tag && (w1 >> 32 << 32) == tag) break;
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > XSPIN_LIMIT) { *a.timeout = 2; break; }
         }
+        a.recv[r * a.cnt + i] = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
     }
-    __threadfence_system();
-    __syncthreads();
-    if (tid < a.nranks * a.cnt) {
-        const int r = tid / a.cnt, i = tid % a.cnt;
-        a.recv[r * a.cnt + i] = sys_load(&a.mbox_local->xval[par][r][i]);
+}
+
+// RCCL transport: fold this rank's block partials of slots [first, first+cnt) into the send buffer
+static __global__ void __launch_bounds__(XBLOCK)
+k_pack(const double* parts, SlotCounts counts, int first, int cnt, unsigned maxmask, double* send) {
+    for (int i = threadIdx.x >> 6; i < cnt; i += XBLOCK / 64) {
+        const double t = fold_wave(parts + (size_t)(first + i) * PSTRIDE, counts.get(i), (maxmask >> i) & 1u);
+        if ((threadIdx.x & 63) == 0) send[first + i] = t;
     }
 }
 
@@ -1478,10 +1524,11 @@ template <class T, int MM> struct CompactVecs {
     int m;
 };
 template <int MM> struct CompactCoef {
-    double M1[MM * MM];
-    double M2[MM * MM];
+    // coefficients of this application, computed by the host from p = S'v, w = Y'v (v = -res) and the Gram
+    // matrices:  u1 = M1 p - H0 M2' w ;  u2h = H0 * (-(M2 p))     (entries beyond m are zero)
+    double u1[MM];
+    double u2h[MM];
     double H0;
-    ScalarSrc psrc[2 * MM];      // p_0..p_{MM-1}, w_0..w_{MM-1}
 };
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
@@ -1512,59 +1559,10 @@ k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* 
     block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
 }
 
-// fold 2*MM scalar sources at once: wave w folds sources w, w+4, ... (fixed order), results in sh_out.
-// All indices into the kernel-argument arrays are compile-time (a run-time index would make the compiler
-// copy the whole argument block to scratch memory in every thread).
-template <int MM>
-__device__ __forceinline__ void fold_many(const ScalarSrc (&srcs)[2 * MM], int m, double* sh_out) {
-    // every thread strides over the partials of ALL sources at once: 2*MM independent, unconditional loads
-    // per step (the host points unused sources at valid memory and gives all sources the same count and
-    // stride), so the whole fold costs about one memory latency instead of one per partial
-    __shared__ double shw[WAVES][2 * MM];
-    double acc[2 * MM];
-#pragma unroll
-    for (int k = 0; k < 2 * MM; ++k) acc[k] = 0.0;
-    const int count = srcs[0].count, stride = srcs[0].stride;
-    for (int i = threadIdx.x; i < count; i += BLOCK) {
-        const size_t off = (size_t)i * stride;
-#pragma unroll
-        for (int k = 0; k < 2 * MM; ++k) acc[k] += srcs[k].p[off];
-    }
-#pragma unroll
-    for (int k = 0; k < 2 * MM; ++k) {
-        const int idx = k < MM ? k : k - MM;
-        const double v = wave_sum(idx < m ? acc[k] : 0.0);
-        if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * MM) {
-        const int k = threadIdx.x;
-        sh_out[k] = (shw[0][k] + shw[1][k]) + (shw[2][k] + shw[3][k]);
-    }
-    __syncthreads();
-}
-
-// coefficients of the compact form for this application: every thread computes the same bits
-//   u1 = M1 p - H0 M2' w ; u2h = H0 * (-(M2 p))      (rows/columns beyond m are zero)
 template <class T, int MM>
-__device__ __forceinline__ void compact_coefs(const CompactCoef<MM>& C, int m, T (&u1)[MM], T (&u2h)[MM]) {
-    __shared__ double pw[2 * MM];
-    fold_many<MM>(C.psrc, m, pw);
-    double p[MM], w[MM];
+__device__ __forceinline__ void compact_coefs(const CompactCoef<MM>& C, T (&u1)[MM], T (&u2h)[MM]) {
 #pragma unroll
-    for (int j = 0; j < MM; ++j) { p[j] = pw[j]; w[j] = pw[MM + j]; }
-#pragma unroll
-    for (int i = 0; i < MM; ++i) {
-        double a = 0.0, b = 0.0, c = 0.0;
-#pragma unroll
-        for (int j = 0; j < MM; ++j) a += C.M1[i * MM + j] * p[j];
-#pragma unroll
-        for (int j = 0; j < MM; ++j) b += C.M2[j * MM + i] * w[j];
-#pragma unroll
-        for (int j = 0; j < MM; ++j) c += C.M2[i * MM + j] * p[j];
-        u1[i] = (T)(a - C.H0 * b);
-        u2h[i] = (T)(C.H0 * (-c));
-    }
+    for (int i = 0; i < MM; ++i) { u1[i] = (T)C.u1[i]; u2h[i] = (T)C.u2h[i]; }
 }
 
 // d for one pack:  d = H0 v + sum u1_i s_i + sum (H0 u2_i) y_i ,  v = -res
@@ -1591,7 +1589,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_compact_xd(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ res,
              const T* __restrict__ x, T* __restrict__ x_d, int64_t n) {
     T u1[MM], u2h[MM];
-    compact_coefs<T, MM>(C, V.m, u1, u2h);
+    compact_coefs<T, MM>(C, u1, u2h);
     const T H0 = (T)C.H0;
     BZ_FOR_EACH_CHUNK(T, n) {
         BZ_CHUNK_VARS(T, n)
@@ -1636,7 +1634,10 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
 // The separable fast path with the compact direction: ONE pass computes d from (res, S, Y), then x_d, both AL
 // gradients, the FB step, the new pair, its Gram products with the stored pairs and the stop norm.
 //   reads : res, S[m], Y[m], x, q, b, mu, mu*y   writes: x_d, z, res, s_new, y_new
-//   slots : slot0 + 0..9 as k_fused_sep ; + 10 + i: <s_i, y_new> ; + 10 + MM + i: <y_i, y_new>
+//   slots : slot0 + 0..9 as k_fused_sep ; + 10 + i: <s_i, y_new> ; + 10 + MM + i: <y_i, y_new> ;
+//           + 10 + 2MM + i: <s_i, -res> ; + 10 + 3MM + i: <y_i, -res> ; then <s_new, -res>, <y_new, -res>
+//           with res the NEW residual: the p and w of the next application, whichever pairs it keeps —
+//           so the whole iteration is this one pass (S and Y are in registers here anyway)
 template <class T, int MM>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
@@ -1644,12 +1645,13 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                 T* __restrict__ z, T* __restrict__ res, T* __restrict__ s_new, T* __restrict__ y_new,
                 int64_t n, double* __restrict__ parts, int slot0) {
     T u1[MM], u2h[MM];
-    compact_coefs<T, MM>(C, V.m, u1, u2h);
+    compact_coefs<T, MM>(C, u1, u2h);
     const T H0 = (T)C.H0;
     const T gl = gamma * P.g_lambda;
-    double acc[10 + 2 * MM];
+    constexpr int NS = 10 + 4 * MM + 2;
+    double acc[NS];
 #pragma unroll
-    for (int k = 0; k < 10 + 2 * MM; ++k) acc[k] = 0.0;
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
     BZ_FOR_EACH_CHUNK(T, n) {
         BZ_CHUNK_VARS(T, n)
         ElemLoads<T> L;
@@ -1695,6 +1697,15 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                         acc[10 + i] += (double)(ps[i].v[e] * yy);
                         acc[10 + MM + i] += (double)(py[i].v[e] * yy);
                     }
+                const T nr = T(-1) * r;
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < V.m) {
+                        acc[10 + 2 * MM + i] += (double)(ps[i].v[e] * nr);
+                        acc[10 + 3 * MM + i] += (double)(py[i].v[e] * nr);
+                    }
+                acc[10 + 4 * MM] += (double)(sv * nr);
+                acc[10 + 4 * MM + 1] += (double)(yy * nr);
             }
         }
         st(x_d, i0, cnt, pxd);
@@ -1703,7 +1714,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         st(s_new, i0, cnt, pss);
         st(y_new, i0, cnt, pyy);
     }
-    block_reduce_store<10 + 2 * MM>(acc, 1u << 9, parts, slot0);
+    block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1922,9 +1933,5 @@ struct CollectArgs {
 // one block per source: fold it and write {scalar, ticket} to the (host-mapped) mailbox `out`; the host
 // spins on the tickets instead of paying a blocking stream synchronisation
 __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out);
-
-// multi-GPU: fold the block partials of slots [first, first+cnt) into send[first+i]
-__global__ void __launch_bounds__(BLOCK)
-k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, double* send);
 
 }  // namespace bz

@@ -46,8 +46,7 @@ constexpr int P2P_PACK = 32;               // doubles per pack exchange
 struct P2PMailbox {                        // layout of one rank's mailbox (all words written by peers)
     double pval[2][P2P_MAXRANKS];                          // persistent-kernel phase totals
     unsigned long long pflag[2][P2P_MAXRANKS];
-    double xval[2][P2P_MAXRANKS][P2P_PACK];                // pack exchanges (k_exchange)
-    unsigned long long xflag[2][P2P_MAXRANKS];
+    unsigned long long xll[2][P2P_MAXRANKS][P2P_PACK][2];  // pack exchanges (k_exchange), tagged half-words
 };
 struct Ctx {
     int device = 0, rank = 0, nranks = 1;
@@ -95,11 +94,12 @@ enum Slot : int {
     SL_FXD = 32, SL_PXD = 33, SL_GSUM = 34, SL_DOT = 35, SL_SS = 36,
     SL_FZ = 37, SL_PZ = 38, SL_YS = 39, SL_YTY = 40, SL_STOP = 41,
     SL_GU = 42,        // compact L-BFGS: Gram products of the new pair, 2*CM slots right behind the trial slots
-    SL_AUX = 52,       // 2 slots: Lipschitz estimate / misc
-    SL_OUTER = 54,     // 2 slots: outer loop
-    SL_SCRATCH = 56,   // sink for partials nobody reads
-    SL_GP = 57,        // compact L-BFGS: p = S'v, w = Y'v, 2*CM slots
-    SL_COUNT = 67
+    SL_GN = 52,        // compact L-BFGS: next p, w (2*CM + 2 slots) right behind them: one exchange for all 32
+    SL_AUX = 64,       // 2 slots: Lipschitz estimate / misc
+    SL_OUTER = 66,     // 2 slots: outer loop
+    SL_SCRATCH = 68,   // sink for partials nobody reads
+    SL_GP = 69,        // compact L-BFGS: p = S'v, w = Y'v from their own pass, 2*CM slots
+    SL_COUNT = 79
 };
 constexpr int MAX_MEM = 16;
 constexpr int CM = 5;            // capacity of the compact L-BFGS form (pairs)

@@ -86,16 +86,6 @@ __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out) {
     }
 }
 
-__global__ void __launch_bounds__(BLOCK)
-k_pack(const double* parts, int grid, int first, int cnt, unsigned maxmask, double* send) {
-    __shared__ double sh[WAVES];
-    for (int i = 0; i < cnt; ++i) {
-        ScalarSrc s{parts + (size_t)(first + i) * PSTRIDE, grid, 1};
-        double t = fold_src(s, (maxmask >> i) & 1u, sh);
-        if (threadIdx.x == 0) send[first + i] = t;
-    }
-}
-
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
                  C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11 };
 
@@ -596,6 +586,11 @@ template <class T> class Solver final : public SolverBase {
     bool compact_ok = false;
     int gm = 0;
     double Gsy[CM * CM], Gyy[CM * CM];
+    // p = S'(-res), w = Y'(-res) at the current state (logical order, oldest first), when the accepted
+    // trial delivered them (k_fused_compact): the next application then needs no reduction pass at all
+    double p_new_ = 0.0, w_new_ = 0.0;      // <s_new, -res>, <y_new, -res> of the candidate pair
+    bool pw_valid = false;
+    double hp_[CM] = {0}, hw_[CM] = {0};
 
     // profiling
     struct ProfRec { int cat; hipEvent_t a, b; };
@@ -626,16 +621,19 @@ template <class T> class Solver final : public SolverBase {
     }
 
     template <class K, class... A> void launch(int cat, K kernel, int g, A... args) {
+        launch_b(cat, kernel, g, BLOCK, args...);
+    }
+    template <class K, class... A> void launch_b(int cat, K kernel, int g, int block, A... args) {
         ProfRec r{cat, nullptr, nullptr};
         const bool prof_on = prof_pick(cat);
         if (prof_on) {
             // start/stop events bound to the dispatch itself: kernel time without the launch gap
             r.a = get_event(); r.b = get_event();
-            hipExtLaunchKernelGGL(kernel, dim3(g), dim3(BLOCK), 0, ctx->stream, r.a, r.b, 0, args...);
+            hipExtLaunchKernelGGL(kernel, dim3(g), dim3(block), 0, ctx->stream, r.a, r.b, 0, args...);
             prof_recs.push_back(r);
             if (prof_recs.size() > 8192) drain_prof();
         } else {
-            hipLaunchKernelGGL(kernel, dim3(g), dim3(BLOCK), 0, ctx->stream, args...);
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(block), 0, ctx->stream, args...);
         }
         BZ_HIP(hipGetLastError());
     }
@@ -678,17 +676,21 @@ template <class T> class Solver final : public SolverBase {
             XchgArgs a;
             std::memset(&a, 0, sizeof(a));
             a.parts = parts_.p; a.first = first; a.cnt = cnt; a.maxmask = maxmask;
-            for (int i = 0; i < cnt; ++i) a.counts[i] = slot_n[first + i];
+            for (int i = 0; i < cnt; ++i) a.counts.set(i, slot_n[first + i]);
             a.rank = ctx->rank; a.nranks = ctx->nranks; a.seq = ++ctx->xseq;
             a.recv = recv_.p + (size_t)first * ctx->nranks;
             a.mbox_local = (P2PWords*)ctx->mbox_local;
             for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
             a.timeout = ptimeout_dev_;
-            launch(C_GATHER, k_exchange, 1, a);
+            launch_b(C_GATHER, k_exchange, 1, XBLOCK, a);
             for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
             return;
         }
-        launch(C_GATHER, k_pack, 1, (const double*)parts_.p, grid, first, cnt, maxmask, send_.p);
+        if (cnt > 32) throw Error(BZ_ERR_ARG, "pack too large");
+        SlotCounts counts;
+        std::memset(&counts, 0, sizeof(counts));
+        for (int i = 0; i < cnt; ++i) counts.set(i, slot_n[first + i]);
+        launch_b(C_GATHER, k_pack, 1, XBLOCK, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p);
         BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
                               ctx->comm, ctx->stream));
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
@@ -699,6 +701,12 @@ template <class T> class Solver final : public SolverBase {
         return ScalarSrc{recv_.p + (size_t)f * ctx->nranks + (slot - f), ctx->nranks, c};
     }
     // fold the listed slots (bit i of maxmask: i-th listed slot is a max) and read them back
+    std::vector<double> collect_range(int first, int cnt, unsigned maxmask) {
+        CollectArgs a;
+        a.n = cnt; a.maxmask = maxmask;
+        for (int i = 0; i < cnt; ++i) a.src[i] = src(first + i);
+        return collect_run(a);
+    }
     std::vector<double> collect(std::initializer_list<int> slots, unsigned maxmask) {
         CollectArgs a;
         a.n = 0; a.maxmask = maxmask;
@@ -706,6 +714,9 @@ template <class T> class Solver final : public SolverBase {
             a.src[a.n] = src(s);
             ++a.n;
         }
+        return collect_run(a);
+    }
+    std::vector<double> collect_run(CollectArgs& a) {
         a.ticket = (double)(++collect_seq);
         launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
         // spin on the tickets in pinned host memory (a few microseconds after the kernel's stores land);
@@ -887,14 +898,14 @@ template <class T> class Solver final : public SolverBase {
         for (int i = 0; i <= M; ++i) { S_[i].alloc(vcap); Y_[i].alloc(vcap); }
     }
     void lbfgs_reset_all() {
-        gm = 0;
+        gm = 0; pw_valid = false;
         order.clear(); freeslots.clear();
         spare = 0;
         for (int i = M; i >= 1; --i) freeslots.push_back(i);
         H = T(1);
     }
     void lbfgs_reset() {                 // reset!(H): currmem = curridx = 0, H = 1
-        gm = 0;
+        gm = 0; pw_valid = false;
         for (int s : order) freeslots.push_back(s);
         order.clear();
         H = T(1);
@@ -906,9 +917,10 @@ template <class T> class Solver final : public SolverBase {
         if (m == M) {                    // the oldest pair is overwritten
             for (int i = 1; i < m; ++i)
                 for (int j = 1; j < m; ++j) { Gsy[(i - 1) * CM + (j - 1)] = Gsy[i * CM + j]; Gyy[(i - 1) * CM + (j - 1)] = Gyy[i * CM + j]; }
-            for (int i = 1; i < m; ++i) { sy[i - 1] = sy[i]; yy[i - 1] = yy[i]; }
+            for (int i = 1; i < m; ++i) { sy[i - 1] = sy[i]; yy[i - 1] = yy[i]; hp_[i - 1] = hp_[i]; hw_[i - 1] = hw_[i]; }
             --m;
         }
+        hp_[m] = p_new_; hw_[m] = w_new_;
         for (int i = 0; i < m; ++i) {
             Gsy[i * CM + m] = sy[i]; Gsy[m * CM + i] = 0.0;
             Gyy[i * CM + m] = yy[i]; Gyy[m * CM + i] = yy[i];
@@ -951,16 +963,34 @@ template <class T> class Solver final : public SolverBase {
         for (int i = 0; i < V.m; ++i) { V.S[i] = S_[order[V.m - 1 - i]].p; V.Y[i] = Y_[order[V.m - 1 - i]].p; }
         return V;
     }
-    // p = S'(-res), w = Y'(-res) and the coefficient block for the kernels that apply the operator
+    // coefficient block for the kernels that apply the operator.  p = S'(-res), w = Y'(-res) normally came
+    // back with the previous iteration's scalars; otherwise (the accepted trial was not the fused one)
+    // they take their own pass and read-back
     CompactCoef<CM> compact_prepare(const CompactVecs<T, CM>& V) {
-        for (int k = 0; k < 2 * CM; ++k) slot_n[SL_GP + k] = grid;
-        launch(C_DOT, k_gram_dots<T, CM>, grid, V, (const T*)RES_[rc].p, n, parts_.p, (int)SL_GP);
-        gather(SL_GP, 2 * CM, 0u);
+        const int m = V.m;
+        if (!pw_valid) {
+            for (int k = 0; k < 2 * CM; ++k) slot_n[SL_GP + k] = grid;
+            launch(C_DOT, k_gram_dots<T, CM>, grid, V, (const T*)RES_[rc].p, n, parts_.p, (int)SL_GP);
+            gather(SL_GP, 2 * CM, 0u);
+            auto pv = collect({SL_GP + 0, SL_GP + 1, SL_GP + 2, SL_GP + 3, SL_GP + 4, SL_GP + 5, SL_GP + 6,
+                               SL_GP + 7, SL_GP + 8, SL_GP + 9}, 0u);
+            for (int i = 0; i < CM; ++i) { hp_[i] = i < m ? pv[i] : 0.0; hw_[i] = i < m ? pv[CM + i] : 0.0; }
+            pw_valid = true;
+        }
         CompactCoef<CM> C;
         std::memset(&C, 0, sizeof(C));
         C.H0 = (double)H;
-        compact_matrices(C.H0, C.M1, C.M2);
-        for (int k = 0; k < 2 * CM; ++k) C.psrc[k] = src(SL_GP + k);   // all valid, same count/stride (fold_many)
+        double M1[CM * CM], M2[CM * CM];
+        compact_matrices(C.H0, M1, M2);
+        // same loops as LBFGSCompactOperator.__call__ (rows/columns beyond m are zero)
+        for (int i = 0; i < CM; ++i) {
+            double a = 0.0, b = 0.0, c = 0.0;
+            for (int j = 0; j < CM; ++j) a += M1[i * CM + j] * (j < m ? hp_[j] : 0.0);
+            for (int j = 0; j < CM; ++j) b += M2[j * CM + i] * (j < m ? hw_[j] : 0.0);
+            for (int j = 0; j < CM; ++j) c += M2[i * CM + j] * (j < m ? hp_[j] : 0.0);
+            C.u1[i] = i < m ? a - C.H0 * b : 0.0;
+            C.u2h[i] = i < m ? C.H0 * (-c) : 0.0;
+        }
         return C;
     }
 
@@ -1199,6 +1229,10 @@ template <class T> class Solver final : public SolverBase {
         if (use_compact) { CV = compact_vecs(); CC = compact_prepare(CV); std::memset(&tail, 0, sizeof(tail)); }
         else tail = use_persist ? two_loop_persist() : two_loop();
         double gsy[CM] = {0}, gyy[CM] = {0};
+        double tp[CM] = {0}, tw[CM] = {0}, tpn = 0.0, twn = 0.0;      // next p, w as measured by the fused trial
+        constexpr int NFC = 10 + 4 * CM + 2;                          // slots of k_fused_compact
+        static_assert(SL_TRIAL + NFC <= SL_AUX, "k_fused_compact's slots overlap the next group");
+        const int m_at_trial = (int)order.size();
         bool gram_from_trial = false;
         tau = T(1);
         const int xp = xc, xd = (xc + 1) % 3, xb = (xc + 2) % 3;
@@ -1209,10 +1243,10 @@ template <class T> class Solver final : public SolverBase {
             // 176 VGPRs -> two 256-thread blocks per CU: one resident round of blocks (each block pays the
             // coefficient prologue and a 20-slot reduction epilogue once)
             const int gfc = std::min(grid, 2 * std::max(1, num_cus));
-            for (int k = 0; k < 10 + 2 * CM; ++k) slot_n[SL_TRIAL + k] = gfc;
+            for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
             launch(C_FUSED, k_fused_compact<T, CM>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
                    gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
-            gather(SL_TRIAL, 10 + 2 * CM, 1u << 9);
+            gather(SL_TRIAL, NFC, 1u << 9);
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
             n_grad += 2; n_prox += 1;
         } else if (fused_ok) {
@@ -1267,10 +1301,12 @@ template <class T> class Solver final : public SolverBase {
                 gather(SL_YS, 3, 4u);
             }
             if (have_trial && gram_from_trial) {
-                v = collect({SL_FXD, SL_PXD, SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_YS, SL_YTY, SL_STOP,
-                             SL_GU + 0, SL_GU + 1, SL_GU + 2, SL_GU + 3, SL_GU + 4, SL_GU + 5, SL_GU + 6, SL_GU + 7,
-                             SL_GU + 8, SL_GU + 9}, 1u << 9);
-                for (int i = 0; i < CM; ++i) { gsy[i] = v[10 + i]; gyy[i] = v[10 + CM + i]; }
+                v = collect_range(SL_TRIAL, NFC, 1u << 9);
+                for (int i = 0; i < CM; ++i) {
+                    gsy[i] = v[10 + i]; gyy[i] = v[10 + CM + i];
+                    tp[i] = v[10 + 2 * CM + i]; tw[i] = v[10 + 3 * CM + i];
+                }
+                tpn = v[10 + 4 * CM]; twn = v[10 + 4 * CM + 1];
             } else {
                 v = collect({SL_FXD, SL_PXD, SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_YS, SL_YTY, SL_STOP},
                             1u << 9);
@@ -1306,6 +1342,13 @@ template <class T> class Solver final : public SolverBase {
         // update!(H, x - x_prev, res - res_prev): the pair sits in the spare slot
         const T ys = T(v[7]), yty = T(v[8]);
         last_ys = ys;
+        // p, w for the next application: valid iff the accepted point is the one the fused trial measured
+        // and the memory was not reset meanwhile (gram_insert shifts them along with the Gram matrices)
+        pw_valid = compact_ok && gram_from_trial && (int)order.size() == m_at_trial;
+        if (pw_valid) {
+            for (int i = 0; i < CM; ++i) { hp_[i] = i < m_at_trial ? tp[i] : 0.0; hw_[i] = i < m_at_trial ? tw[i] : 0.0; }
+            p_new_ = tpn; w_new_ = twn;
+        }
         if (ys > T(0)) {
             if (compact_ok && !gram_from_trial && !order.empty()) {
                 // the accepted pair is not the one the fused trial measured: its Gram products with the

@@ -284,27 +284,38 @@ def test_float32_path(bz, ref):
     prob.close()
 
 
-def test_allgather_plumbing_single_rank(bz, ref):
-    """The multi-GPU scalar path (k_pack -> RCCL all-gather -> fold over ranks) on a 1-rank
-    communicator must reproduce the single-GPU iterates bit for bit."""
-    n = 30011
+@pytest.mark.parametrize("variant", ["two-loop", "compact", "nofuse", "large-compact", "large-two-loop"])
+def test_allgather_plumbing_single_rank(bz, ref, variant):
+    """The multi-GPU scalar paths on ONE rank — k_pack -> RCCL all-gather -> fold over ranks, and the
+    self-loop of the peer-to-peer mailboxes — must reproduce the no-communicator iterates bit for bit
+    (the per-rank fold is the same fold, in the same order).  'large' sizes use capped grids, so slots
+    written by different kernels hold different numbers of block partials."""
+    n = 600_011 if variant.startswith("large") else 30011
     d, dev, orc = make_cfg2(bz, ref, n)
     rng = np.random.default_rng(2)
     mu = np.full(n, 0.1)
     y = rng.standard_normal(n)
+    # persist=False: the persistent two-loop kernel folds 256 block partials, the kernel chain 2048 — the
+    # transports must be compared on the same kernels
+    opts = bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=variant != "nofuse", persist=False,
+                        directions=bz.LBFGS(5, compact="compact" in variant)).c_opts()
     res = []
-    for with_comm in (False, True):
-        ctx = bz.Context(device=0, rank=0, nranks=1, comm_id=bz.Context.unique_id() if with_comm else None)
+    for transport in ("none", "rccl", "p2p"):
+        ctx = bz.Context(device=0, rank=0, nranks=1, comm_id=bz.Context.unique_id() if transport == "rccl" else None)
+        if transport == "p2p":
+            ctx.p2p_connect([ctx.p2p_export()], [0])
         prob = bz.Problem(*dev, n, n, np.float64, ctx)
         prob.set_multipliers(mu, y)
-        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n))
-        for _ in range(12):
+        prob.panoc_begin(opts, np.zeros(n))
+        for _ in range(14):
             prob.panoc_step()
-        res.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars()))
+        res.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(), prob.panoc_stats()))
         prob.close()
         ctx.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    assert res[0][2]["stop_norm"] == res[1][2]["stop_norm"] and res[0][2]["gamma"] == res[1][2]["gamma"]
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1])
+        assert res[0][2]["stop_norm"] == other[2]["stop_norm"] and res[0][2]["gamma"] == other[2]["gamma"]
+        assert res[0][3].n_grad == other[3].n_grad and res[0][3].n_backtracks == other[3].n_backtracks
 
 
 def test_full_size_properties(bz, ref):

@@ -10,8 +10,16 @@ fuse = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 persist = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 compact = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 d = bz.synth.l1_quadratic(n)
+# QB_XCHG=p2p|rccl: a 1-rank context that still runs every scalar exchange (self-loop mailboxes / 1-rank
+# communicator): the per-iteration cost of the multi-GPU code path minus the xGMI hop
+ctx = None
+if os.environ.get("QB_XCHG") == "p2p":
+    ctx = bz.Context(device=0, rank=0, nranks=1)
+    ctx.p2p_connect([ctx.p2p_export()], [0])
+elif os.environ.get("QB_XCHG") == "rccl":
+    ctx = bz.Context(device=0, rank=0, nranks=1, comm_id=bz.Context.unique_id())
 prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
-                  bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), n, n, np.float64)
+                  bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), n, n, np.float64, ctx)
 print(prob.ctx.info())
 mu = np.full(n, 0.1); y = np.zeros(n)
 prob.set_multipliers(mu, y)

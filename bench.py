@@ -271,8 +271,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-states", type=int, default=31)
     ap.add_argument("--no-fuse", action="store_true")
-    ap.add_argument("--compact", action="store_true", help="compact L-BFGS form also at N = 1")
-    ap.add_argument("--two-loop", action="store_true", help="N > 1: keep the two-loop form (11 exchanges per iteration)")
+    ap.add_argument("--compact", action="store_true", help="(default) compact L-BFGS representation")
+    ap.add_argument("--two-loop", action="store_true",
+                    help="evaluate the L-BFGS operator by the two-loop recursion in the reference's operation order "
+                         "(2M sequential reductions: 11 exchanges per iteration at N > 1)")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the two-loop and outer-iteration-3 side measurements")
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: keep the RCCL all-gather for the scalar exchange")
     args = ap.parse_args()
 
@@ -306,18 +309,20 @@ def main():
     lo_i, hi_i = bz.shard_bounds(n, rank, world)
     nl = hi_i - lo_i
     d = bz.synth.l1_quadratic(nl, start=lo_i)
-    # N > 1: the L-BFGS operator is evaluated in its compact form (one reduction phase per application
-    # instead of 2M sequential ones: 2 cross-GPU exchanges per iteration instead of 11).  Same operator,
-    # alternate rounding (oracle: LBFGSCompactOperator; tests: test_compact_lbfgs_*).
-    compact = (world > 1 and not args.two_loop) or args.compact
+    # The L-BFGS operator is evaluated in its compact representation: the whole iteration is ONE pass over
+    # 2M + 11 vectors and one reduction phase (one cross-GPU exchange at N > 1), against 2M sequential
+    # reductions for the two-loop recursion.  Same operator, alternate rounding — its iterates stay as close
+    # to the fp64 oracle's as the two-loop kernels' do (oracle: LBFGSCompactOperator; tests:
+    # test_compact_lbfgs_*; tools/err_compact_vs_twoloop.py).  --two-loop times the reference's order.
+    compact = not args.two_loop
     popts = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),
                          fuse=not args.no_fuse, directions=bz.LBFGS(M_LBFGS, compact=compact)).c_opts()
 
-    def make_problem(c):
+    def make_problem(c, po=None, mu=None, y=None):
         p = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
                        bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), nl, nl, np.float64, c)
-        p.set_multipliers(np.full(nl, 0.1), np.zeros(nl))
-        p.panoc_begin(popts, np.zeros(nl))
+        p.set_multipliers(np.full(nl, 0.1) if mu is None else mu, np.zeros(nl) if y is None else y)
+        p.panoc_begin(po or popts, np.zeros(nl))
         return p
 
     # N > 1: scalar exchange through peer-to-peer mailboxes (no collective call; the persistent two-loop
@@ -366,41 +371,72 @@ def main():
                 ctx, transport = ctx2, "p2p"
         if transport != "p2p" and p2p_note is None:
             p2p_note = "p2p rejected on another rank"
-    prob = make_problem(ctx)
-    del d
-
     def barrier():
         ctx.synchronize()
         if grp is not None:
             grp.barrier()
         ctx.synchronize()
 
-    # HIP events bound to each dispatch on the library's own stream (hipExtLaunchKernelGGL start/stop
-    # events).  Warm-up: every kernel category is timed, to find the dominant kernel and fill the
-    # per-kernel table; timed region: only the dominant kernel carries events (one launch per iteration).
     ALG = ("k_twoloop_persist", "k_axpy_dot", "k_fused_sep", "k_dot")
-    prob.profile_reset()
-    prob.profile_enable(os.environ.get("BZ_BENCH_WARMPROF", "1") == "1")
-    for _ in range(args.warmup):
-        prob.panoc_step()
-    prof_warm = prob.profile()
-    cands = {k: v for k, v in prof_warm.items() if k in ALG and v["launches"]}
-    dom = max(cands, key=lambda k: cands[k]["total_ms"]) if cands else "k_axpy_dot"
-    prob.profile_reset()
-    prob.profile_enable(1 << bz._lib.KERNEL_CATEGORIES.index(dom), period=int(os.environ.get("BZ_BENCH_PERIOD", "8")))
-    st0 = prob.panoc_stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        prob.panoc_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prob.profile_enable(False)
-    if grp is not None:
-        elapsed = grp.reduce(elapsed, max)
-    st1 = prob.panoc_stats()
-    sc = prob.panoc_scalars()
-    prof_all = prob.profile()
+
+    def timed_run(prob, steps, warmup):
+        """W untimed + K timed iterations on `prob`.  HIP events bound to each dispatch on the library's own
+        stream (hipExtLaunchKernelGGL start/stop events): in the warm-up every kernel category is timed, to
+        find the dominant kernel and fill the per-kernel table; in the timed region only every 8th launch of
+        the dominant kernel carries events, so they do not perturb the pipeline."""
+        prob.profile_reset()
+        prob.profile_enable(os.environ.get("BZ_BENCH_WARMPROF", "1") == "1")
+        for _ in range(warmup):
+            prob.panoc_step()
+        prof_warm = prob.profile()
+        cands = {k: v for k, v in prof_warm.items() if k in ALG and v["launches"]}
+        dom = max(cands, key=lambda k: cands[k]["total_ms"]) if cands else "k_axpy_dot"
+        prob.profile_reset()
+        prob.profile_enable(1 << bz._lib.KERNEL_CATEGORIES.index(dom), period=int(os.environ.get("BZ_BENCH_PERIOD", "8")))
+        st0 = prob.panoc_stats()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            prob.panoc_step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prob.profile_enable(False)
+        if grp is not None:
+            elapsed = grp.reduce(elapsed, max)
+        return {"elapsed": elapsed, "st0": st0, "st1": prob.panoc_stats(), "sc": prob.panoc_scalars(),
+                "prof": prob.profile(), "prof_warm": prof_warm, "dom": dom}
+
+    prob = make_problem(ctx)
+    R = timed_run(prob, args.steps, args.warmup)
+    prob.close()
+    elapsed, st0, st1, sc, prof_all, prof_warm, dom = (R[k] for k in ("elapsed", "st0", "st1", "sc", "prof", "prof_warm", "dom"))
+
+    # N = 1 extras (rank 0 prints them beside the headline, they never replace it):
+    #   two_loop : the same workload with the L-BFGS operator in the reference's two-loop operation order
+    #   outer3   : the same workload inside outer iteration 3 (mu, y after two ALPS outer iterations: y != 0),
+    #              SURVEY §8(d)
+    extras = {}
+    if world == 1 and not args.no_extras:
+        if compact:
+            popts_tl = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),
+                                    fuse=not args.no_fuse, directions=bz.LBFGS(M_LBFGS)).c_opts()
+            p2 = make_problem(ctx, popts_tl)
+            r2 = timed_run(p2, args.steps, args.warmup)
+            p2.close()
+            extras["two_loop"] = {"value": round(args.steps / r2["elapsed"], 3), "unit": "iterations/s",
+                                  "ms_per_step": round(1e3 * r2["elapsed"] / args.steps, 5),
+                                  "note": "directions=LBFGS(5) evaluated by the two-loop recursion in the reference's operation "
+                                          "order (persistent register-resident kernel); same iterates up to rounding"}
+        out3 = bz.alps(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                       bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), np.zeros(nl), np.zeros(nl), maxit=2, ctx=ctx)
+        p3 = make_problem(ctx, None, out3[9], out3[1])
+        r3 = timed_run(p3, args.steps, args.warmup)
+        p3.close()
+        extras["outer3"] = {"value": round(args.steps / r3["elapsed"], 3), "unit": "iterations/s",
+                            "ms_per_step": round(1e3 * r3["elapsed"] / args.steps, 5),
+                            "note": "same workload with (mu, y) as left by two ALPS outer iterations (max|y| = %.3g)"
+                                    % float(np.max(np.abs(out3[1])))}
+    del d
 
     if rank == 0:
         its = args.steps / elapsed
@@ -414,14 +450,17 @@ def main():
         #   k_twoloop_persist : the two-loop minus its last axpy = (8m+1) - 4 passes      (moves 4m)
         #   k_axpy_dot        : 3R+1W per step, the middle step 2R+1W -> (8m-5)/(2m-1) passes on average
         #   k_fused_sep       : last axpy + x_d (4) + 2 AL gradients (2*6) + FB step (4) + update/stop (8)
+        #   k_fused_compact   : the WHOLE iteration is this one launch: (8m+1) + 12 + 4 + 8 = 65 passes at m = 5
+        #                       (it moves 2m + 11 = 21: reads res, S[m], Y[m], x, q, b, mu, mu*y; writes x_d, z,
+        #                       res, s, y; the next application's S'res, Y'res come out of the same pass)
         alg_passes = {"k_twoloop_persist": (8 * m + 1) - 4,
                       "k_axpy_dot": (4.0 * (2 * m - 2) + 3.0) / (2 * m - 1) if m >= 1 else 0.0,
                       "k_fused_sep": 4 + 12 + 4 + 8, "k_dot": 2}
+        real_name = dom
         if compact:
-            # compact form: k_gram_dots reads res + S[m] + Y[m]; k_fused_compact reads res, S[m], Y[m], x, q, b,
-            # mu, mu*y and writes x_d, z, res, s, y — the model's two-loop share (8m+1 passes) is split between them
             alg_passes["k_dot"] = 2 * m + 1
-            alg_passes["k_fused_sep"] = (8 * m + 1) - (2 * m + 1) + 12 + 4 + 8
+            alg_passes["k_fused_sep"] = (8 * m + 1) + 12 + 4 + 8
+            real_name = {"k_fused_sep": "k_fused_compact", "k_dot": "k_gram_dots"}.get(dom, dom)
         prof = prof_all[dom]
         launches_per_it = (st1.n_fused_iters - st0.n_fused_iters) / max(1, args.steps) if dom != "k_axpy_dot" else 9.0
         bytes_per_launch = alg_passes[dom] * w * nl
@@ -432,8 +471,7 @@ def main():
         if os.path.exists(pmc) and world == 1 and n == 10_000_000:
             with open(pmc) as fh:
                 pj = json.load(fh)
-            if pj.get("kernel") == dom:
-                traffic = pj.get("hbm_bytes_per_launch")
+            traffic = pj.get("kernels", {}).get(real_name)
         b_iter = algorithmic_bytes_per_iter(n, n_al=2, n_fb=1)
         out = {
             "metric": "PANOC inner iterations/sec, n=10^7 l1-quadratic" if n == 10_000_000 else "PANOC inner iterations/sec, n=%d l1-quadratic" % n,
@@ -448,12 +486,11 @@ def main():
                        f"x sharded over {world} GPUs, scalars exchanged by " +
                        ("peer-to-peer mailboxes over xGMI" if transport == "p2p" else "RCCL all-gather"),
                        "scalar_transport": transport, "p2p_note": p2p_note,
-                       "lbfgs_form": "compact (1 reduction phase per application)" if compact
-                       else "two-loop (persistent kernel, 2M-1 grid phases)"},
+                       "lbfgs_form": "compact representation: one pass and one reduction phase per iteration" if compact
+                       else "two-loop recursion (persistent kernel, 2M-1 grid phases)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "bz::%s<double>" % ({"k_fused_sep": "k_fused_compact", "k_dot": "k_gram_dots"}.get(dom, dom)
-                                                         if compact else dom), "launches_per_iteration": round(launches_per_it, 2),
+                         "kernel": "bz::%s<double>" % real_name, "launches_per_iteration": round(launches_per_it, 2),
                          "avg_launch_us": round(avg_s * 1e6, 3), "timed_launches": prof["launches"],
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "algorithmic_passes_per_launch": round(alg_passes[dom], 3),
@@ -472,12 +509,12 @@ def main():
                        "lbfgs_mem": m, "gamma": sc["gamma"], "stop_norm": sc["stop_norm"],
                        "k": int(sc["k"])},
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_states)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    prob.close()
     ctx.close()
     if grp is not None:
         grp.barrier()

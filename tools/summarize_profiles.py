@@ -57,17 +57,11 @@ def main(tag="r01"):
                               "--no-cpu-baseline (two separate passes)",
                    "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
                    "n": 10_000_000, "kernels": summary}, fh, indent=1)
-    # the kernel bench.py reports as dominant (largest total time in the stats run)
-    dom = None
-    if stats:
-        best = max((r for r in rows if "k_twoloop_persist" in r["Name"] or "k_axpy_dot" in r["Name"] or "k_fused_sep" in r["Name"]),
-                   key=lambda r: float(r["TotalDurationNs"]))
-        dom = short(best["Name"])
-    if dom and dom in summary:
-        key = dom.replace("bz::", "").split("<")[0]
+    # what bench.py looks up for roofline.traffic: measured HBM bytes per launch, by kernel
+    if summary:
         with open(os.path.join(out_dir, "pmc_dominant_kernel.json"), "w") as fh:
-            json.dump({"kernel": key, "n": 10_000_000, "hbm_bytes_per_launch": summary[dom]["hbm_bytes_per_launch"],
-                       "source": f"profiles/{tag}_pmc_hbm_traffic_n1e7.json"}, fh)
+            json.dump({"n": 10_000_000, "source": f"profiles/{tag}_pmc_hbm_traffic_n1e7.json",
+                       "kernels": {k.replace("bz::", "").split("<")[0]: v["hbm_bytes_per_launch"] for k, v in summary.items()}}, fh, indent=1)
     print(json.dumps(summary, indent=1))
 
 

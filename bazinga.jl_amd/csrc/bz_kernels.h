@@ -170,6 +170,40 @@ __device__ __forceinline__ void st(T* __restrict__ p, int64_t i0, int cnt, const
             if (e < cnt) p[i0 + e] = r.v[e];
     }
 }
+// non-temporal forms (streamed once per launch: do not displace what the caches hold)
+template <class T> struct PackVec;
+template <> struct PackVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct PackVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <class T, bool NT>
+__device__ __forceinline__ Pack<T> ldp(const T* __restrict__ p, int64_t i0, int cnt) {
+    if constexpr (!NT) return ld(p, i0, cnt);
+    constexpr int N = PackN<T>::N;
+    Pack<T> r;
+    if (cnt == N) {
+        typename PackVec<T>::type v = __builtin_nontemporal_load(reinterpret_cast<const typename PackVec<T>::type*>(p + i0));
+#pragma unroll
+        for (int e = 0; e < N; ++e) r.v[e] = v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) r.v[e] = (e < cnt) ? p[i0 + e] : T(1);
+    }
+    return r;
+}
+template <class T, bool NT>
+__device__ __forceinline__ void stp(T* __restrict__ p, int64_t i0, int cnt, const Pack<T>& r) {
+    if constexpr (!NT) { st(p, i0, cnt, r); return; }
+    constexpr int N = PackN<T>::N;
+    if (cnt == N) {
+        typename PackVec<T>::type v;
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = r.v[e];
+        __builtin_nontemporal_store(v, reinterpret_cast<typename PackVec<T>::type*>(p + i0));
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+            if (e < cnt) p[i0 + e] = r.v[e];
+    }
+}
 template <class T> __device__ __forceinline__ Pack<T> splat(T s) {
     Pack<T> r;
 #pragma unroll
@@ -313,23 +347,23 @@ template <class T> struct ElemLoads {
     Pack<T> q, b, mu, muy, dlo, dhi, gu, glo, ghi;
 };
 
-template <class T>
+template <class T, bool NT = false>
 __device__ __forceinline__ void load_params(const ElemParams<T>& P, int64_t i0, int cnt,
                                             ElemLoads<T>& L, bool need_f, bool need_al,
                                             bool need_g) {
     L.q = splat(T(0)); L.b = splat(T(0));
-    if (need_f && P.f_kind == BZ_F_DIAG_QUADRATIC) { L.q = ld(P.q, i0, cnt); L.b = ld(P.b, i0, cnt); }
+    if (need_f && P.f_kind == BZ_F_DIAG_QUADRATIC) { L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt); }
     if (need_al) {
-        L.mu = ld(P.mu, i0, cnt);
-        L.muy = ld(P.muy, i0, cnt);
-        L.dlo = P.D_lo_vec ? ld(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
-        L.dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
+        L.mu = ldp<T, NT>(P.mu, i0, cnt);
+        L.muy = ldp<T, NT>(P.muy, i0, cnt);
+        L.dlo = P.D_lo_vec ? ldp<T, NT>(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
+        L.dhi = P.D_hi_vec ? ldp<T, NT>(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
     }
     if (need_g) {
         L.gu = (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX || P.g_kind == BZ_G_NORM_LP_BOX)
-                   ? ld(P.g_u, i0, cnt) : splat(T(0));
-        L.glo = P.g_lo_vec ? ld(P.g_lo_vec, i0, cnt) : splat(P.g_lo);
-        L.ghi = P.g_hi_vec ? ld(P.g_hi_vec, i0, cnt) : splat(P.g_hi);
+                   ? ldp<T, NT>(P.g_u, i0, cnt) : splat(T(0));
+        L.glo = P.g_lo_vec ? ldp<T, NT>(P.g_lo_vec, i0, cnt) : splat(P.g_lo);
+        L.ghi = P.g_hi_vec ? ldp<T, NT>(P.g_hi_vec, i0, cnt) : splat(P.g_hi);
     }
 }
 
@@ -904,6 +938,56 @@ static __global__ void __launch_bounds__(XBLOCK) k_exchange(XchgArgs a) {
             if (++spins > XSPIN_LIMIT) { *a.timeout = 2; break; }
         }
         a.recv[r * a.cnt + i] = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
+    }
+}
+
+// k_exchange that also folds the packs over the ranks (rank order: identical bits everywhere) and hands the
+// totals to the host's pinned mailbox as {value, ticket} pairs: exchange + read-back in ONE launch
+struct XCollectArgs {
+    XchgArgs x;
+    double* host_out;
+    double ticket;
+};
+static __global__ void __launch_bounds__(XBLOCK) k_exchange_collect(XCollectArgs b) {
+    const XchgArgs& a = b.x;
+    __shared__ double vals[32];
+    __shared__ double got[8][32];
+    const int tid = threadIdx.x;
+    for (int i = tid >> 6; i < a.cnt; i += XBLOCK / 64) {
+        const double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
+        if ((tid & 63) == 0) vals[i] = t;
+    }
+    __syncthreads();
+    const int par = (int)(a.seq & 1ull);
+    const unsigned long long tag = (unsigned long long)ll_tag(a.seq) << 32;
+    if (tid < a.nranks * a.cnt) {
+        const int r = tid / a.cnt, i = tid % a.cnt;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[i]);
+        unsigned long long* dst = a.mbox_peer[r]->xll[par][a.rank][i];
+        sys_store(dst + 0, tag | (bits & 0xFFFFFFFFull));
+        sys_store(dst + 1, tag | (bits >> 32));
+        const unsigned long long* src = a.mbox_local->xll[par][r][i];
+        unsigned long long w0, w1;
+        unsigned spins = 0;
+        for (;;) {
+            w0 = sys_load(src + 0);
+            w1 = sys_load(src + 1);
+            if ((w0 >> 32 << 32) == tag && (w1 >> 32 << 32) == tag) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > XSPIN_LIMIT) { *a.timeout = 2; break; }
+        }
+        const double v = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
+        got[r][i] = v;
+        a.recv[r * a.cnt + i] = v;
+    }
+    __syncthreads();
+    if (tid < a.cnt) {
+        const bool ismax = (a.maxmask >> tid) & 1u;
+        double g = 0.0;
+        for (int r = 0; r < a.nranks; ++r) g = ismax ? nanmax(g, got[r][tid]) : g + got[r][tid];
+        __hip_atomic_store(b.host_out + 2 * tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();                       // value before ticket
+        __hip_atomic_store(b.host_out + 2 * tid + 1, b.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1638,7 +1722,7 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
 //           + 10 + 2MM + i: <s_i, -res> ; + 10 + 3MM + i: <y_i, -res> ; then <s_new, -res>, <y_new, -res>
 //           with res the NEW residual: the p and w of the next application, whichever pairs it keeps —
 //           so the whole iteration is this one pass (S and Y are in registers here anyway)
-template <class T, int MM>
+template <class T, int MM, bool NT>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
@@ -1655,11 +1739,11 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     BZ_FOR_EACH_CHUNK(T, n) {
         BZ_CHUNK_VARS(T, n)
         ElemLoads<T> L;
-        load_params(P, i0, cnt, L, true, true, true);
-        Pack<T> px = ld(x, i0, cnt), prp = ld(res_prev, i0, cnt), ps[MM], py[MM], d;
+        load_params<T, NT>(P, i0, cnt, L, true, true, true);
+        Pack<T> px = ldp<T, NT>(x, i0, cnt), prp = ldp<T, NT>(res_prev, i0, cnt), ps[MM], py[MM], d;
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < V.m) { ps[i] = ld(V.S[i], i0, cnt); py[i] = ld(V.Y[i], i0, cnt); }
+            if (i < V.m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
         compact_d<T, MM>(V, H0, u1, u2h, prp, ps, py, d);
         Pack<T> pxd, pz, pr, pss, pyy;
 #pragma unroll
@@ -1708,11 +1792,11 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                 acc[10 + 4 * MM + 1] += (double)(yy * nr);
             }
         }
-        st(x_d, i0, cnt, pxd);
-        st(z, i0, cnt, pz);
-        st(res, i0, cnt, pr);
-        st(s_new, i0, cnt, pss);
-        st(y_new, i0, cnt, pyy);
+        stp<T, NT>(x_d, i0, cnt, pxd);
+        stp<T, NT>(z, i0, cnt, pz);
+        stp<T, NT>(res, i0, cnt, pr);
+        stp<T, NT>(s_new, i0, cnt, pss);
+        stp<T, NT>(y_new, i0, cnt, pyy);
     }
     block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
 }

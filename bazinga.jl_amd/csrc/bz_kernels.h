@@ -15,6 +15,7 @@
 // Per-element arithmetic mirrors the CPU oracle operation for operation (build with
 // -ffp-contract=off), so element-wise outputs are bit-identical to oracle/.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -212,16 +213,20 @@ template <class T> __device__ __forceinline__ Pack<T> splat(T s) {
 }
 
 // canonical element->thread map shared by every kernel, so that a quantity summed
-// by two different kernels is summed in the same order (fused == unfused, bitwise)
-#define BZ_FOR_EACH_CHUNK(T, n)                                                         \
-    for (int64_t _c = (int64_t)blockIdx.x * BLOCK + threadIdx.x,                        \
-                 _nc = ((n) + PackN<T>::N - 1) / PackN<T>::N,                           \
-                 _st = (int64_t)gridDim.x * BLOCK;                                      \
-         _c < _nc; _c += _st)
-
-#define BZ_CHUNK_VARS(T, n)                                                             \
-    const int64_t i0 = _c * PackN<T>::N;                                                \
-    const int cnt = (i0 + PackN<T>::N <= (n)) ? PackN<T>::N : (int)((n) - i0);
+// by two different kernels is summed in the same order (fused == unfused, bitwise):
+// chunk c (PackN elements) belongs to thread c mod (grid*BLOCK), chunks in increasing order.
+// The body is instantiated twice: for full chunks `cnt` is the compile-time PackN (no tail branches,
+// straight-line loads), and once for the ragged last chunk of the vector, which is also the last chunk
+// of the thread that owns it.
+template <class T, class F>
+__device__ __forceinline__ void bz_for_chunks(int64_t n, F&& f) {
+    constexpr int N = PackN<T>::N;
+    const int64_t nfull = n / N;
+    const int64_t st = (int64_t)gridDim.x * BLOCK;
+    int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    for (; c < nfull; c += st) f(c * N, std::integral_constant<int, N>{});
+    if (c == nfull && nfull * N < n) f(c * N, (int)(n - nfull * N));
+}
 
 // ---------------------------------------------------------------------------
 // element-wise oracle arithmetic (mirrors oracle/bazinga_ref.py and oracle/c)
@@ -420,8 +425,8 @@ k_axpy_dot(TailArgs<T> a, const T* w, const T* xadd, T* out /* may alias a.in */
     __shared__ double sh[WAVES];
     const T coef = tail_coef(a, sh);
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pin = ld(a.in, i0, cnt);
         Pack<T> pv = (a.mode != 2) ? ld(a.v, i0, cnt) : splat(T(0));
         Pack<T> pw = w ? ld(w, i0, cnt) : splat(T(0));
@@ -435,7 +440,7 @@ k_axpy_dot(TailArgs<T> a, const T* w, const T* xadd, T* out /* may alias a.in */
             if (w && e < cnt) acc[0] += (double)(pw.v[e] * o);
         }
         st(out, i0, cnt, po);
-    }
+    });
     if (w) block_reduce_store<1>(acc, 0u, parts, slot_out);
 }
 
@@ -445,13 +450,13 @@ __global__ void __launch_bounds__(BLOCK)
 k_dot(const T* __restrict__ a, const T* __restrict__ b, T sgn, int64_t n,
       double* __restrict__ parts, int slot_out) {
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pa = ld(a, i0, cnt), pb = ld(b, i0, cnt);
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e)
             if (e < cnt) acc[0] += (double)(pa.v[e] * (sgn * pb.v[e]));
-    }
+    });
     block_reduce_store<1>(acc, 0u, parts, slot_out);
 }
 
@@ -469,8 +474,8 @@ k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, in
               double* __restrict__ parts, int slot0, int fext, const T* __restrict__ ext) {
     double acc[2] = {0.0, 0.0};
     const int fk = fext ? BZ_F_ZERO : P.f_kind;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
         load_params(P, i0, cnt, L, fext == 0, true, false);
         Pack<T> px = ld(x, i0, cnt), pg;
@@ -491,7 +496,7 @@ k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, in
             if (e < cnt) { acc[0] += (double)o.fterm; acc[1] += (double)o.pterm; }
         }
         if (grad) st(grad, i0, cnt, pg);
-    }
+    });
     if (fext == 1) {
         double a1[1] = {acc[1]};
         block_reduce_store<1>(a1, 0u, parts, slot0 + 1);
@@ -557,12 +562,12 @@ __global__ void __launch_bounds__(BLOCK)
 k_algrad_stencil(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, int f_only,
                  T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
     double acc[2] = {0.0, 0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> xc = ld(x, i0, cnt);
         Pack<T> pg = stencil_al_pack(x, P, nx, ny, f_only, i0, cnt, xc, acc[0], acc[1]);
         if (grad) st(grad, i0, cnt, pg);
-    }
+    });
     block_reduce_store<2>(acc, 0u, parts, slot0);
 }
 
@@ -577,8 +582,8 @@ k_stencil_fb(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, T
              double* __restrict__ parts, int slot_f, int slot_g) {
     double accF[2] = {0.0, 0.0}, accG[3] = {0.0, 0.0, 0.0};
     const T gl = gamma * P.g_lambda;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> xc = ld(x, i0, cnt);
         Pack<T> pg = stencil_al_pack(x, P, nx, ny, 0, i0, cnt, xc, accF[0], accF[1]);
         ElemLoads<T> L;
@@ -601,7 +606,7 @@ k_stencil_fb(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, T
         st(grad, i0, cnt, pg);
         st(z, i0, cnt, pz);
         st(res, i0, cnt, pr);
-    }
+    });
     block_reduce_store<2>(accF, 0u, parts, slot_f);
     block_reduce_store<3>(accG, 0u, parts, slot_g);
 }
@@ -617,8 +622,8 @@ k_stencil_update(const T* __restrict__ zp, ElemParams<T> P, int64_t nx, int64_t 
                  T* __restrict__ s_new, T* __restrict__ y_new, T* __restrict__ gz_out, int64_t n,
                  double* __restrict__ parts, int slot_f, int slot_u) {
     double accF[2] = {0.0, 0.0}, accU[3] = {0.0, 0.0, 0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> zc = ld(zp, i0, cnt);
         Pack<T> pgz = stencil_al_pack(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1]);
         Pack<T> px = ld(x, i0, cnt), pxp = ld(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ld(res_prev, i0, cnt);
@@ -640,7 +645,7 @@ k_stencil_update(const T* __restrict__ zp, ElemParams<T> P, int64_t nx, int64_t 
         st(s_new, i0, cnt, ps);
         st(y_new, i0, cnt, py);
         if (gz_out) st(gz_out, i0, cnt, pgz);
-    }
+    });
     block_reduce_store<2>(accF, 0u, parts, slot_f);
     __syncthreads();
     block_reduce_store<3>(accU, 4u, parts, slot_u);
@@ -697,8 +702,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_yupd(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ yupd, int64_t ny,
        double* __restrict__ parts, int slot0) {
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, ny) {
-        BZ_CHUNK_VARS(T, ny)
+    bz_for_chunks<T>(ny, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
         load_params(P, i0, cnt, L, false, true, false);
         Pack<T> pc = ld(cx, i0, cnt), py;
@@ -712,7 +717,7 @@ k_yupd(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ yupd, int64_t 
             if (e < cnt) acc[0] += (double)pterm;
         }
         st(yupd, i0, cnt, py);
-    }
+    });
     block_reduce_store<1>(acc, 0u, parts, slot0);
 }
 
@@ -817,8 +822,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_gemv_t_finish(const T* __restrict__ part, int nchunks, int64_t pstride, const T* __restrict__ x,
                 ElemParams<T> P, T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> j = ld(part, i0, cnt);
         for (int k = 1; k < nchunks; ++k) {
             Pack<T> q = ld(part + (int64_t)k * pstride, i0, cnt);
@@ -839,7 +844,7 @@ k_gemv_t_finish(const T* __restrict__ part, int nchunks, int64_t pstride, const 
             if (e < cnt) acc[0] += (double)fterm;
         }
         if (grad) st(grad, i0, cnt, pg);
-    }
+    });
     block_reduce_store<1>(acc, 0u, parts, slot0);
 }
 
@@ -1349,8 +1354,8 @@ k_fbstep(const T* __restrict__ x, const T* __restrict__ g, T gamma, ElemParams<T
          int slot0) {
     double acc[3] = {0.0, 0.0, 0.0};
     const T gl = gamma * P.g_lambda;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
         load_params(P, i0, cnt, L, false, false, true);
         Pack<T> px = ld(x, i0, cnt);
@@ -1372,7 +1377,7 @@ k_fbstep(const T* __restrict__ x, const T* __restrict__ g, T gamma, ElemParams<T
         }
         st(z, i0, cnt, pz);
         if (res) st(res, i0, cnt, pr);
-    }
+    });
     block_reduce_store<3>(acc, 0u, parts, slot0);
 }
 
@@ -1388,8 +1393,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_algrad_slack_elem(const T* __restrict__ xs, ElemParams<T> P, const T* __restrict__ yv,
                     T* __restrict__ grad, int64_t nx, double* __restrict__ parts, int slot0) {
     double acc[2] = {0.0, 0.0};
-    BZ_FOR_EACH_CHUNK(T, nx) {
-        BZ_CHUNK_VARS(T, nx)
+    bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> px = ld(xs, i0, cnt), ps = ld(xs + nx, i0, cnt);
         Pack<T> pq = splat(T(0)), pb = splat(T(0));
         if (P.f_kind == BZ_F_DIAG_QUADRATIC) { pq = ld(P.q, i0, cnt); pb = ld(P.b, i0, cnt); }
@@ -1415,7 +1420,7 @@ k_algrad_slack_elem(const T* __restrict__ xs, ElemParams<T> P, const T* __restri
             if (e < cnt) { acc[0] += (double)fterm; acc[1] += (double)pterm; }
         }
         if (grad) { st(grad, i0, cnt, gx); st(grad + nx, i0, cnt, gs); }
-    }
+    });
     block_reduce_store<2>(acc, 0u, parts, slot0);
 }
 
@@ -1429,8 +1434,8 @@ k_fbstep_slack(const T* __restrict__ xs, const T* __restrict__ g, T gamma, ElemP
                int slot0) {
     double acc[3] = {0.0, 0.0, 0.0};
     const T gl = gamma * P.g_lambda;
-    BZ_FOR_EACH_CHUNK(T, nx) {
-        BZ_CHUNK_VARS(T, nx)
+    bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
         load_params(P, i0, cnt, L, false, false, true);
         Pack<T> dlo = P.D_lo_vec ? ld(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
@@ -1457,7 +1462,7 @@ k_fbstep_slack(const T* __restrict__ xs, const T* __restrict__ g, T gamma, ElemP
         }
         st(z, i0, cnt, zx); st(z + nx, i0, cnt, zs);
         if (res) { st(res, i0, cnt, rx); st(res + nx, i0, cnt, rs); }
-    }
+    });
     block_reduce_store<3>(acc, 0u, parts, slot0);
 }
 
@@ -1467,8 +1472,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_dual_update_slack(const T* __restrict__ xs, const T* __restrict__ mu, T* __restrict__ y,
                     int64_t nx, double* __restrict__ parts, int slot0) {
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, nx) {
-        BZ_CHUNK_VARS(T, nx)
+    bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> px = ld(xs, i0, cnt), ps = ld(xs + nx, i0, cnt), pm = ld(mu, i0, cnt), py = ld((const T*)y, i0, cnt);
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
@@ -1477,7 +1482,7 @@ k_dual_update_slack(const T* __restrict__ xs, const T* __restrict__ mu, T* __res
             if (e < cnt) acc[0] = nanmax(acc[0], (double)(r < T(0) ? -r : r));
         }
         st(y, i0, cnt, py);
-    }
+    });
     block_reduce_store<1>(acc, 1u, parts, slot0);
 }
 
@@ -1493,8 +1498,8 @@ k_update(const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restr
          T gamma, T* __restrict__ s_new, T* __restrict__ y_new, int64_t n,
          double* __restrict__ parts, int slot0) {
     double acc[3] = {0.0, 0.0, 0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> px = ld(x, i0, cnt), pr = ld(res, i0, cnt);
         Pack<T> pxp = x_prev ? ld(x_prev, i0, cnt) : px;
         Pack<T> prp = res_prev ? ld(res_prev, i0, cnt) : pr;
@@ -1515,7 +1520,7 @@ k_update(const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restr
             }
         }
         if (s_new) { st(s_new, i0, cnt, ps); st(y_new, i0, cnt, py); }
-    }
+    });
     block_reduce_store<3>(acc, 4u, parts, slot0);
 }
 
@@ -1541,8 +1546,8 @@ k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_pr
     double acc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
         load_params(P, i0, cnt, L, true, true, true);
         Pack<T> pin = ld(a.in, i0, cnt);
@@ -1589,7 +1594,7 @@ k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_pr
         st(y_new, i0, cnt, py);
         if (gx_out) st(gx_out, i0, cnt, pg1);
         if (gz_out) st(gz_out, i0, cnt, pg2);
-    }
+    });
     block_reduce_store<10>(acc, 1u << 9, parts, slot0);
 }
 
@@ -1623,8 +1628,8 @@ k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* 
     double acc[2 * MM];
 #pragma unroll
     for (int k = 0; k < 2 * MM; ++k) acc[k] = 0.0;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pr = ld(res, i0, cnt);
 #pragma unroll
         for (int i = 0; i < MM; ++i) {
@@ -1639,7 +1644,7 @@ k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* 
                     }
             }
         }
-    }
+    });
     block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
 }
 
@@ -1675,8 +1680,8 @@ k_compact_xd(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ res,
     T u1[MM], u2h[MM];
     compact_coefs<T, MM>(C, u1, u2h);
     const T H0 = (T)C.H0;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pres = ld(res, i0, cnt), px = ld(x, i0, cnt), ps[MM], py[MM], d, o;
 #pragma unroll
         for (int i = 0; i < MM; ++i)
@@ -1685,7 +1690,7 @@ k_compact_xd(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ res,
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) o.v[e] = px.v[e] + d.v[e];
         st(x_d, i0, cnt, o);
-    }
+    });
 }
 
 // Gram products of a (new) pair with the stored ones: <s_i, y_new> -> slot0 + i, <y_i, y_new> -> slot0 + MM + i
@@ -1696,8 +1701,8 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
     double acc[2 * MM];
 #pragma unroll
     for (int k = 0; k < 2 * MM; ++k) acc[k] = 0.0;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pn = ld(y_new, i0, cnt);
 #pragma unroll
         for (int i = 0; i < MM; ++i) {
@@ -1711,7 +1716,7 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
                     }
             }
         }
-    }
+    });
     block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
 }
 
@@ -1736,8 +1741,8 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
         load_params<T, NT>(P, i0, cnt, L, true, true, true);
         Pack<T> px = ldp<T, NT>(x, i0, cnt), prp = ldp<T, NT>(res_prev, i0, cnt), ps[MM], py[MM], d;
@@ -1797,7 +1802,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         stp<T, NT>(res, i0, cnt, pr);
         stp<T, NT>(s_new, i0, cnt, pss);
         stp<T, NT>(y_new, i0, cnt, pyy);
-    }
+    });
     block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
 }
 
@@ -1809,8 +1814,8 @@ template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_blend(const T* __restrict__ x_d, const T* __restrict__ z_curr, T tau, T omt,
         T* __restrict__ x, int64_t n) {
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> a = ld(x_d, i0, cnt), b = ld(z_curr, i0, cnt), o;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
@@ -1819,20 +1824,20 @@ k_blend(const T* __restrict__ x_d, const T* __restrict__ z_curr, T tau, T omt,
             o.v[e] = p + q;
         }
         st(x, i0, cnt, o);
-    }
+    });
 }
 
 // out = in + c
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_add_scalar(const T* __restrict__ in, T c, T* __restrict__ out, int64_t n) {
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> a = ld(in, i0, cnt), o;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) o.v[e] = a.v[e] + c;
         st(out, i0, cnt, o);
-    }
+    });
 }
 
 // slots: +0 sum (a-b)^2, +1 sum (c-d)^2     (lower_bound_smoothness_constant)
@@ -1841,8 +1846,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_diff_ss2(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
            const T* __restrict__ d, int64_t n, double* __restrict__ parts, int slot0) {
     double acc[2] = {0.0, 0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pa = ld(a, i0, cnt), pb = ld(b, i0, cnt), pc = ld(c, i0, cnt), pd = ld(d, i0, cnt);
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e)
@@ -1852,7 +1857,7 @@ k_diff_ss2(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict
                 acc[0] += (double)(u * u);
                 acc[1] += (double)(v * v);
             }
-    }
+    });
     block_reduce_store<2>(acc, 0u, parts, slot0);
 }
 
@@ -1866,8 +1871,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_muy(const T* __restrict__ mu, const T* __restrict__ y, T* __restrict__ muy, int64_t n,
       double* __restrict__ parts, int slot0) {
     double acc[2] = {0.0, 0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pm = ld(mu, i0, cnt), py = ld(y, i0, cnt), o;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
@@ -1879,7 +1884,7 @@ k_muy(const T* __restrict__ mu, const T* __restrict__ y, T* __restrict__ muy, in
             }
         }
         st(muy, i0, cnt, o);
-    }
+    });
     block_reduce_store<2>(acc, 2u, parts, slot0);
 }
 
@@ -1890,8 +1895,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_dual_update(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ y, T* __restrict__ s,
               int64_t n, double* __restrict__ parts, int slot0) {
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
         load_params(P, i0, cnt, L, false, true, false);
         Pack<T> pc = ld(cx, i0, cnt), py, ps;
@@ -1907,7 +1912,7 @@ k_dual_update(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ y, T* _
         }
         st(y, i0, cnt, py);
         st(s, i0, cnt, ps);
-    }
+    });
     block_reduce_store<1>(acc, 1u, parts, slot0);
 }
 
@@ -1917,8 +1922,8 @@ template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_penalty_init(const T* __restrict__ cx, ElemParams<T> P, double denom, T* __restrict__ s,
                T* __restrict__ mu, int64_t n) {
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pc = ld(cx, i0, cnt), ps, pm;
         Pack<T> dlo = P.D_lo_vec ? ld(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
         Pack<T> dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
@@ -1937,15 +1942,15 @@ k_penalty_init(const T* __restrict__ cx, ElemParams<T> P, double denom, T* __res
         }
         st(s, i0, cnt, ps);
         st(mu, i0, cnt, pm);
-    }
+    });
 }
 
 // v = clamp(v, lo, hi)  (default_dual_safeguard!) ; v *= c
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_clamp_scale(T* __restrict__ v, double lo, double hi, T scale, int do_clamp, int64_t n) {
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> a = ld((const T*)v, i0, cnt), o;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
@@ -1961,7 +1966,7 @@ k_clamp_scale(T* __restrict__ v, double lo, double hi, T scale, int do_clamp, in
             o.v[e] = t;
         }
         st(v, i0, cnt, o);
-    }
+    });
 }
 
 // slot +0: max |v|   (verbose display: ||res||_inf)
@@ -1969,13 +1974,13 @@ template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_absmax(const T* __restrict__ v, int64_t n, double* __restrict__ parts, int slot0) {
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> a = ld(v, i0, cnt);
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e)
             if (e < cnt) acc[0] = nanmax(acc[0], (double)(a.v[e] < T(0) ? -a.v[e] : a.v[e]));
-    }
+    });
     block_reduce_store<1>(acc, 1u, parts, slot0);
 }
 
@@ -1985,8 +1990,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_fvalue_elem(const T* __restrict__ x, ElemParams<T> P, int64_t n, double* __restrict__ parts,
               int slot0, const T* __restrict__ ext) {
     double acc[1] = {0.0};
-    BZ_FOR_EACH_CHUNK(T, n) {
-        BZ_CHUNK_VARS(T, n)
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> px = ld(x, i0, cnt);
         Pack<T> q = splat(T(0)), b = splat(T(0));
         if (P.f_kind == BZ_F_DIAG_QUADRATIC) { q = ld(P.q, i0, cnt); b = ld(P.b, i0, cnt); }
@@ -2000,7 +2005,7 @@ k_fvalue_elem(const T* __restrict__ x, ElemParams<T> P, int64_t n, double* __res
                 acc[0] += (double)(px.v[e] * (T(0.5) * qx - b.v[e]));
             }
         }
-    }
+    });
     block_reduce_store<1>(acc, 0u, parts, slot0);
 }
 

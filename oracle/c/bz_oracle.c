@@ -24,6 +24,17 @@
 
 typedef double real;
 
+/* cpu_baseline "all cores" build (oracle/Makefile: libbz_oracle_omp.so, -fopenmp): the SAME
+ * reference-shaped loops, each one split over the host threads; reductions become per-thread partial
+ * sums (a different rounding — this build is only ever timed, never used as a checker). */
+#ifdef _OPENMP
+#define PFOR _Pragma("omp parallel for schedule(static)")
+#define PRED_ACC _Pragma("omp parallel for schedule(static) reduction(+:acc)")
+#else
+#define PFOR
+#define PRED_ACC
+#endif
+
 enum { D_ZERO = 0, D_FREE = 1, D_BOX = 2 };
 enum { G_ZERO = 0, G_L1 = 1, G_L1_NONNEG = 2, G_L1_BOX = 3, G_IND_BOX = 4 };
 
@@ -43,6 +54,14 @@ typedef struct {
 
 /* ---- Julia Base reductions, restated: pairwise sum with 1024-element leaves */
 static real pairwise_sum(const real* v, int64_t n) {
+#ifdef _OPENMP
+    {
+        real s = 0;
+        _Pragma("omp parallel for schedule(static) reduction(+:s)")
+        for (int64_t i = 0; i < n; ++i) s += v[i];
+        return s;
+    }
+#endif
     if (n <= 1024) {
         real s = 0;
         for (int64_t i = 0; i < n; ++i) s += v[i];
@@ -53,6 +72,9 @@ static real pairwise_sum(const real* v, int64_t n) {
 }
 static real dot(const real* a, const real* b, int64_t n) {   /* BLAS ddot shape: 1 pass */
     real s = 0;
+#ifdef _OPENMP
+    _Pragma("omp parallel for schedule(static) reduction(+:s)")
+#endif
     for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
 }
@@ -61,16 +83,16 @@ static real norm2(const real* a, int64_t n) { return sqrt(dot(a, a, n)); }
 /* ---- oracles ------------------------------------------------------------- */
 static void proj_D(const AL* al, real* s, const real* v) {
     const int64_t n = al->n;
-    if (al->D_kind == D_ZERO) { for (int64_t i = 0; i < n; ++i) s[i] = 0; }
-    else if (al->D_kind == D_FREE) { for (int64_t i = 0; i < n; ++i) s[i] = v[i]; }
-    else { for (int64_t i = 0; i < n; ++i) s[i] = v[i] < al->D_lo ? al->D_lo : (v[i] > al->D_hi ? al->D_hi : v[i]); }
+    if (al->D_kind == D_ZERO) { PFOR for (int64_t i = 0; i < n; ++i) s[i] = 0; }
+    else if (al->D_kind == D_FREE) { PFOR for (int64_t i = 0; i < n; ++i) s[i] = v[i]; }
+    else { PFOR for (int64_t i = 0; i < n; ++i) s[i] = v[i] < al->D_lo ? al->D_lo : (v[i] > al->D_hi ? al->D_hi : v[i]); }
 }
 static real f_gradient(const AL* al, real* dfx, const real* x) {
     const int64_t n = al->n;
     real fx = 0;
-    if (!al->q) { for (int64_t i = 0; i < n; ++i) dfx[i] = 0; return 0; }
+    if (!al->q) { PFOR for (int64_t i = 0; i < n; ++i) dfx[i] = 0; return 0; }
     real* t = al->tmp;
-    for (int64_t i = 0; i < n; ++i) { real qx = al->q[i] * x[i]; dfx[i] = qx - al->b[i]; t[i] = x[i] * (0.5 * qx - al->b[i]); }
+    PFOR for (int64_t i = 0; i < n; ++i) { real qx = al->q[i] * x[i]; dfx[i] = qx - al->b[i]; t[i] = x[i] * (0.5 * qx - al->b[i]); }
     fx = pairwise_sum(t, n);
     return fx;
 }
@@ -80,22 +102,22 @@ static real g_prox(const AL* al, real* z, const real* x, real gamma) {
     real acc = 0;
     switch (al->g_kind) {
     case G_L1:
-        for (int64_t i = 0; i < n; ++i) {
+        PRED_ACC for (int64_t i = 0; i < n; ++i) {
             z[i] = x[i] + (x[i] <= -gl ? gl : (x[i] >= gl ? -gl : -x[i]));
             acc += z[i] > 0 ? z[i] : -z[i];
         }
         return al->lam * acc;
     case G_L1_NONNEG:
-        for (int64_t i = 0; i < n; ++i) { if (x[i] >= gl) { z[i] = x[i] - gl; acc += z[i]; } else z[i] = 0; }
+        PRED_ACC for (int64_t i = 0; i < n; ++i) { if (x[i] >= gl) { z[i] = x[i] - gl; acc += z[i]; } else z[i] = 0; }
         return al->lam * acc;
     case G_L1_BOX:
-        for (int64_t i = 0; i < n; ++i) { real a = x[i] - gl; a = a < al->g_u[i] ? a : al->g_u[i]; z[i] = a > 0 ? a : 0; acc += z[i]; }
+        PRED_ACC for (int64_t i = 0; i < n; ++i) { real a = x[i] - gl; a = a < al->g_u[i] ? a : al->g_u[i]; z[i] = a > 0 ? a : 0; acc += z[i]; }
         return al->lam * acc;
     case G_IND_BOX:
-        for (int64_t i = 0; i < n; ++i) z[i] = x[i] < al->g_lo ? al->g_lo : (x[i] > al->g_hi ? al->g_hi : x[i]);
+        PFOR for (int64_t i = 0; i < n; ++i) z[i] = x[i] < al->g_lo ? al->g_lo : (x[i] > al->g_hi ? al->g_hi : x[i]);
         return 0;
     default:
-        for (int64_t i = 0; i < n; ++i) z[i] = x[i];
+        PFOR for (int64_t i = 0; i < n; ++i) z[i] = x[i];
         return 0;
     }
 }
@@ -104,18 +126,18 @@ static real g_prox(const AL* al, real* z, const real* x, real gamma) {
 static real al_gradient(AL* al, real* dlx, const real* x) {
     const int64_t n = al->n;
     al->n_grad++;
-    for (int64_t i = 0; i < n; ++i) al->cx[i] = x[i];                       /* eval!(cx, c, x)          */
-    for (int64_t i = 0; i < n; ++i) al->yupd[i] = al->cx[i] + al->muy[i];   /* yupd .= cx .+ muy        */
+    PFOR for (int64_t i = 0; i < n; ++i) al->cx[i] = x[i];                       /* eval!(cx, c, x)          */
+    PFOR for (int64_t i = 0; i < n; ++i) al->yupd[i] = al->cx[i] + al->muy[i];   /* yupd .= cx .+ muy        */
     proj_D(al, al->s, al->yupd);                                            /* proj!(s, D, yupd)        */
-    for (int64_t i = 0; i < n; ++i) al->yupd[i] -= al->s[i];                /* yupd .-= s               */
-    for (int64_t i = 0; i < n; ++i) al->tmp[i] = (al->yupd[i] * al->yupd[i]) / al->mu[i];  /* temp  */
+    PFOR for (int64_t i = 0; i < n; ++i) al->yupd[i] -= al->s[i];                /* yupd .-= s               */
+    PFOR for (int64_t i = 0; i < n; ++i) al->tmp[i] = (al->yupd[i] * al->yupd[i]) / al->mu[i];  /* temp  */
     real lx = 0.5 * pairwise_sum(al->tmp, n);                               /* 0.5*sum(...)             */
-    for (int64_t i = 0; i < n; ++i) al->yupd[i] /= al->mu[i];               /* yupd ./= mu              */
+    PFOR for (int64_t i = 0; i < n; ++i) al->yupd[i] /= al->mu[i];               /* yupd ./= mu              */
     al->fx = f_gradient(al, al->dfx, x);                                    /* gradient!(dfx, f, x)     */
     lx += al->fx;
     lx -= al->musqy;
-    for (int64_t i = 0; i < n; ++i) al->jtv[i] = al->yupd[i];               /* jtprod!(jtv, c, x, yupd) */
-    for (int64_t i = 0; i < n; ++i) dlx[i] = al->dfx[i] + al->jtv[i];       /* dlx .= dfx .+ jtv        */
+    PFOR for (int64_t i = 0; i < n; ++i) al->jtv[i] = al->yupd[i];               /* jtprod!(jtv, c, x, yupd) */
+    PFOR for (int64_t i = 0; i < n; ++i) dlx[i] = al->dfx[i] + al->jtv[i];       /* dlx .= dfx .+ jtv        */
     return lx;
 }
 
@@ -145,16 +167,16 @@ static void lbfgs_mul(LBFGS* L, real* d, const real* v, int64_t n) {
         real a = dot(L->s_M[idx - 1], d, n) / L->ys_M[idx - 1];
         L->alphas[idx - 1] = a;
         const real* y = L->y_M[idx - 1];
-        for (int64_t k = 0; k < n; ++k) d[k] -= a * y[k];
+        PFOR for (int64_t k = 0; k < n; ++k) d[k] -= a * y[k];
         idx -= 1; if (idx == 0) idx = L->M;
     }
-    for (int64_t k = 0; k < n; ++k) d[k] = L->H * d[k];
+    PFOR for (int64_t k = 0; k < n; ++k) d[k] = L->H * d[k];
     for (int i = 0; i < L->currmem; ++i) {
         idx += 1; if (idx > L->M) idx = 1;
         real beta = dot(L->y_M[idx - 1], d, n) / L->ys_M[idx - 1];
         real c = L->alphas[idx - 1] - beta;
         const real* s = L->s_M[idx - 1];
-        for (int64_t k = 0; k < n; ++k) d[k] += c * s[k];
+        PFOR for (int64_t k = 0; k < n; ++k) d[k] += c * s[k];
     }
 }
 
@@ -183,8 +205,8 @@ int bzo_panoc_run(int64_t n, const real* q, const real* b, int g_kind, real lam,
     /* AugLagUpdate! (auglagfun.jl:91-101) */
     for (int64_t i = 0; i < n; ++i) { if (mu_in[i] <= 0) return -6; }
     memcpy(al.mu, mu_in, nb); memcpy(al.y, y_in, nb);
-    for (int64_t i = 0; i < n; ++i) al.muy[i] = al.mu[i] * al.y[i];
-    for (int64_t i = 0; i < n; ++i) al.tmp[i] = al.muy[i] * al.y[i];
+    PFOR for (int64_t i = 0; i < n; ++i) al.muy[i] = al.mu[i] * al.y[i];
+    PFOR for (int64_t i = 0; i < n; ++i) al.tmp[i] = al.muy[i] * al.y[i];
     al.musqy = 0.5 * pairwise_sum(al.tmp, n);
 
     real *x, *gx, *yv, *z, *res, *x_prev, *res_prev, *d, *x_d, *gxd, *z_curr, *gz, *t1, *t2;
@@ -198,15 +220,15 @@ int bzo_panoc_run(int64_t n, const real* q, const real* b, int g_kind, real lam,
     /* Base.iterate(iter) */
     memcpy(x, x0, nb);
     real f_x = al_gradient(&al, gx, x);
-    for (int64_t i = 0; i < n; ++i) t1[i] = x[i] + 1;                 /* xeps = x .+ 1 */
+    PFOR for (int64_t i = 0; i < n; ++i) t1[i] = x[i] + 1;                 /* xeps = x .+ 1 */
     al_gradient(&al, t2, t1);
-    for (int64_t i = 0; i < n; ++i) t2[i] = t2[i] - gx[i];
+    PFOR for (int64_t i = 0; i < n; ++i) t2[i] = t2[i] - gx[i];
     real nrm_g = norm2(t2, n);
-    for (int64_t i = 0; i < n; ++i) t2[i] = t1[i] - x[i];
+    PFOR for (int64_t i = 0; i < n; ++i) t2[i] = t1[i] - x[i];
     real gamma = alpha / (nrm_g / norm2(t2, n));
-    for (int64_t i = 0; i < n; ++i) yv[i] = x[i] - gamma * gx[i];
+    PFOR for (int64_t i = 0; i < n; ++i) yv[i] = x[i] - gamma * gx[i];
     real g_z = g_prox(&al, z, yv, gamma);
-    for (int64_t i = 0; i < n; ++i) res[i] = x[i] - z[i];
+    PFOR for (int64_t i = 0; i < n; ++i) res[i] = x[i] - z[i];
     int64_t n_bt = 0, n_halv = 0;
     real tau = 0;
     real f_z;
@@ -216,9 +238,9 @@ int bzo_panoc_run(int64_t n, const real* q, const real* b, int g_kind, real lam,
         real tol = 10 * eps * (1 + fabs(f_z));
         while (f_z > f_z_upp + tol && gamma >= minimum_gamma) {
             gamma /= 2; n_halv++;
-            for (int64_t i = 0; i < n; ++i) yv[i] = x[i] - gamma * gx[i];
+            PFOR for (int64_t i = 0; i < n; ++i) yv[i] = x[i] - gamma * gx[i];
             g_z = g_prox(&al, z, yv, gamma);
-            for (int64_t i = 0; i < n; ++i) res[i] = x[i] - z[i];
+            PFOR for (int64_t i = 0; i < n; ++i) res[i] = x[i] - z[i];
             f_z_upp = f_model(f_x, gx, res, alpha / gamma, n);
             f_z = al_gradient(&al, gz, z);
             tol = 10 * eps * (1 + fabs(f_z));
@@ -227,18 +249,22 @@ int bzo_panoc_run(int64_t n, const real* q, const real* b, int g_kind, real lam,
     real stop = 0;
     for (int64_t k = 1;; ++k) {
         /* default_stopping_criterion: norm(res/gamma - gx + gz, Inf)  (allocating broadcast) */
-        for (int64_t i = 0; i < n; ++i) t1[i] = res[i] / gamma - gx[i] + gz[i];
-        stop = 0; for (int64_t i = 0; i < n; ++i) { real a = fabs(t1[i]); if (a > stop || a != a) stop = a; }
+        PFOR for (int64_t i = 0; i < n; ++i) t1[i] = res[i] / gamma - gx[i] + gz[i];
+        stop = 0;
+#ifdef _OPENMP
+        _Pragma("omp parallel for schedule(static) reduction(max:stop)")
+#endif
+        for (int64_t i = 0; i < n; ++i) { real a = fabs(t1[i]); if (a > stop || a != a) stop = a; }
         if (trace) { trace[4 * (k - 1) + 0] = gamma; trace[4 * (k - 1) + 1] = f_x; trace[4 * (k - 1) + 2] = g_z; trace[4 * (k - 1) + 3] = stop; }
         if (k >= iters) break;
         /* Base.iterate(iter, state) */
         memcpy(x_prev, x, nb); memcpy(res_prev, res, nb);
         real FBE_x = f_model(f_x, gx, res, alpha / gamma, n) + g_z;
-        for (int64_t i = 0; i < n; ++i) t1[i] = -res[i];              /* -state.res (allocates) */
+        PFOR for (int64_t i = 0; i < n; ++i) t1[i] = -res[i];              /* -state.res (allocates) */
         lbfgs_mul(&L, d, t1, n);
         tau = 1;
         memcpy(t2, d, nb);                                            /* mul!(Ad, I, d)         */
-        for (int64_t i = 0; i < n; ++i) x_d[i] = x[i] + d[i];
+        PFOR for (int64_t i = 0; i < n; ++i) x_d[i] = x[i] + d[i];
         real f_xd = al_gradient(&al, gxd, x_d);
         memcpy(x, x_d, nb); memcpy(gx, gxd, nb); f_x = f_xd;
         memcpy(z_curr, z, nb);
@@ -247,9 +273,9 @@ int bzo_panoc_run(int64_t n, const real* q, const real* b, int g_kind, real lam,
         real nr = norm2(res, n);
         real threshold = FBE_x - sigma * (nr * nr) + tol;
         for (int kk = 1; kk <= max_bt; ++kk) {
-            for (int64_t i = 0; i < n; ++i) yv[i] = x[i] - gamma * gx[i];
+            PFOR for (int64_t i = 0; i < n; ++i) yv[i] = x[i] - gamma * gx[i];
             g_z = g_prox(&al, z, yv, gamma);
-            for (int64_t i = 0; i < n; ++i) res[i] = x[i] - z[i];
+            PFOR for (int64_t i = 0; i < n; ++i) res[i] = x[i] - z[i];
             real f_z_upp = f_model(f_x, gx, res, alpha / gamma, n);
             f_z = al_gradient(&al, gz, z);
             tol = 10 * eps * (1 + fabs(f_z));
@@ -261,11 +287,11 @@ int bzo_panoc_run(int64_t n, const real* q, const real* b, int g_kind, real lam,
             real FBE_new = f_z_upp + g_z;
             if (FBE_new <= threshold || kk >= max_bt) break;
             tau = (kk >= max_bt - 1) ? 0 : tau / 2; n_bt++;
-            for (int64_t i = 0; i < n; ++i) x[i] = tau * x_d[i] + (1 - tau) * z_curr[i];
+            PFOR for (int64_t i = 0; i < n; ++i) x[i] = tau * x_d[i] + (1 - tau) * z_curr[i];
             f_x = al_gradient(&al, gx, x);
         }
-        for (int64_t i = 0; i < n; ++i) t1[i] = x[i] - x_prev[i];
-        for (int64_t i = 0; i < n; ++i) t2[i] = res[i] - res_prev[i];
+        PFOR for (int64_t i = 0; i < n; ++i) t1[i] = x[i] - x_prev[i];
+        PFOR for (int64_t i = 0; i < n; ++i) t2[i] = res[i] - res_prev[i];
         real ys;
         lbfgs_update(&L, t1, t2, n, &ys);
     }

@@ -293,6 +293,10 @@ def main():
                          "(2M sequential reductions: 11 exchanges per iteration at N > 1)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the two-loop and outer-iteration-3 side measurements")
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: keep the RCCL all-gather for the scalar exchange")
+    ap.add_argument("--no-rccl", action="store_true",
+                    help="N > 1: do not create the RCCL communicator (p2p mailboxes only, checked for rank agreement "
+                         "instead of against RCCL).  With BZ_BENCH_SAME_GPU=1 (all ranks on device 0) this rehearses "
+                         "the N > 1 path on a one-GPU box, where RCCL refuses two ranks on one device")
     args = ap.parse_args()
 
     import bazinga_jl_amd as bz
@@ -317,10 +321,27 @@ def main():
         except Exception as e:      # noqa: BLE001
             print(f"[bench] TCP rendezvous failed ({e!r}); using torch.distributed", file=sys.stderr, flush=True)
             grp = TorchGroup(rank, world, local_rank)
-        ids = grp.allgather(bz.Context.unique_id() if rank == 0 else b"")
-        comm_id = ids[0]
+        if not args.no_rccl:
+            ids = grp.allgather(bz.Context.unique_id() if rank == 0 else b"")
+            comm_id = ids[0]
     dev = local_rank if world > 1 else 0
-    ctx = bz.Context(device=dev, rank=rank, nranks=world, comm_id=comm_id)
+    if os.environ.get("BZ_BENCH_SAME_GPU") == "1":
+        dev = 0
+
+    def agree(flag):
+        return grp.reduce(flag, min) >= 1 if grp is not None else bool(flag)
+
+    ctx, rccl_note = None, None
+    try:
+        if world == 1 or comm_id is not None:
+            ctx = bz.Context(device=dev, rank=rank, nranks=world, comm_id=comm_id)
+    except Exception as e:      # noqa: BLE001
+        rccl_note = f"RCCL communicator failed: {e!r}"[:300]
+        print(f"[bench] rank {rank}: {rccl_note}", file=sys.stderr, flush=True)
+    if world > 1 and not agree(ctx is not None):
+        if ctx is not None:
+            ctx.close()
+        ctx = None                              # no RCCL on this node: the p2p transport or nothing
 
     lo_i, hi_i = bz.shard_bounds(n, rank, world)
     nl = hi_i - lo_i
@@ -344,12 +365,10 @@ def main():
     # N > 1: scalar exchange through peer-to-peer mailboxes (no collective call; the persistent two-loop
     # kernel runs sharded).  It is taken only if it reproduces the RCCL path's scalars on this node;
     # otherwise the RCCL all-gather path (always correct, slower) is timed.
-    transport = "none" if world == 1 else "rccl"
+    transport = "none" if world == 1 else ("rccl" if ctx is not None else None)
     p2p_note = None
-    if world > 1 and not args.no_p2p:
-        def agree(flag):
-            return grp.reduce(flag, min) >= 1
-
+    ctx_rccl = None
+    if world > 1 and not (args.no_p2p and ctx is not None):
         ok, ctx2 = 1, None
         try:                                    # stage 1: map everybody's mailbox
             ctx2 = bz.Context(device=dev, rank=rank, nranks=world, comm_id=None)
@@ -366,32 +385,58 @@ def main():
                 ok, p2p_note = 0, f"p2p connect failed: {e!r}"[:300]
         else:
             ok = 0
-        if agree(ok):                           # stage 2: same scalars as the RCCL path after 8 iterations
-            pa = make_problem(ctx)
-            for _ in range(8):
-                pa.panoc_step()
-            sa = pa.panoc_scalars()
-            pa.close()
+        if agree(ok):                           # stage 2: 8 iterations, same scalars as the RCCL path
+            keys = ("gamma", "f_x", "g_z", "stop_norm", "FBE")
+            sa = None
+            if ctx is not None:
+                pa = make_problem(ctx)
+                for _ in range(8):
+                    pa.panoc_step()
+                sa = pa.panoc_scalars()
+                pa.close()
+            sb = None
             try:
                 pb = make_problem(ctx2)
                 for _ in range(8):
                     pb.panoc_step()
                 sb = pb.panoc_scalars()
                 pb.close()
-                for key in ("gamma", "f_x", "g_z", "stop_norm", "FBE"):
-                    if not abs(sa[key] - sb[key]) <= 1e-9 * max(1.0, abs(sa[key])):
-                        ok, p2p_note = 0, f"p2p/rccl mismatch on {key}: {sb[key]} vs {sa[key]}"
+                if sa is not None:
+                    for key in keys:
+                        if not abs(sa[key] - sb[key]) <= 1e-9 * max(1.0, abs(sa[key])):
+                            ok, p2p_note = 0, f"p2p/rccl mismatch on {key}: {sb[key]} vs {sa[key]}"
+                if not all(np.isfinite(sb[key]) for key in keys):
+                    ok, p2p_note = 0, "p2p run produced non-finite scalars"
             except Exception as e:      # noqa: BLE001  (a peer never answered: every rank times out alike)
                 ok, p2p_note = 0, f"p2p run failed: {e!r}"[:300]
+            # every rank must hold the same bits (they take the line-search decisions independently)
+            mine = repr([sb[key] for key in keys]).encode() if sb is not None else b"none"
+            if len(set(grp.allgather(mine))) != 1:
+                ok, p2p_note = 0, p2p_note or "ranks disagree on the p2p scalars"
             if agree(ok):
+                if ctx is not None:
+                    ctx_rccl = ctx
                 ctx, transport = ctx2, "p2p"
+                if sa is None:
+                    p2p_note = "p2p checked for rank agreement only (no RCCL communicator: " + (rccl_note or "--no-rccl") + ")"
         if transport != "p2p" and p2p_note is None:
             p2p_note = "p2p rejected on another rank"
-    def barrier():
-        ctx.synchronize()
+    if ctx is None:
+        raise SystemExit(f"[bench] no working scalar transport at N={world}: {rccl_note}; {p2p_note}")
+    def sync(ok=1):
+        """Barrier + device drain that carries a health flag: the SAME group operation on every rank whatever
+        happened locally, so one rank's failure cannot leave the others waiting in a different collective."""
+        try:
+            ctx.synchronize()
+        except Exception:       # noqa: BLE001
+            ok = 0
         if grp is not None:
-            grp.barrier()
-        ctx.synchronize()
+            ok = 1 if grp.reduce(ok, min) >= 1 else 0
+        try:
+            ctx.synchronize()
+        except Exception:       # noqa: BLE001
+            ok = 0
+        return ok
 
     ALG = ("k_twoloop_persist", "k_axpy_dot", "k_fused_sep", "k_dot")
 
@@ -400,30 +445,49 @@ def main():
         stream (hipExtLaunchKernelGGL start/stop events): in the warm-up every kernel category is timed, to
         find the dominant kernel and fill the per-kernel table; in the timed region only every 8th launch of
         the dominant kernel carries events, so they do not perturb the pipeline."""
-        prob.profile_reset()
-        prob.profile_enable(os.environ.get("BZ_BENCH_WARMPROF", "1") == "1")
-        for _ in range(warmup):
-            prob.panoc_step()
-        prof_warm = prob.profile()
-        cands = {k: v for k, v in prof_warm.items() if k in ALG and v["launches"]}
-        dom = max(cands, key=lambda k: cands[k]["total_ms"]) if cands else "k_axpy_dot"
-        prob.profile_reset()
-        prob.profile_enable(1 << bz._lib.KERNEL_CATEGORIES.index(dom), period=int(os.environ.get("BZ_BENCH_PERIOD", "8")))
-        st0 = prob.panoc_stats()
-        barrier()
+        ok, err, prof_warm, dom, st0 = 1, None, {}, "k_axpy_dot", None
+        try:
+            prob.profile_reset()
+            prob.profile_enable(os.environ.get("BZ_BENCH_WARMPROF", "1") == "1")
+            for _ in range(warmup):
+                prob.panoc_step()
+            prof_warm = prob.profile()
+            cands = {k: v for k, v in prof_warm.items() if k in ALG and v["launches"]}
+            dom = max(cands, key=lambda k: cands[k]["total_ms"]) if cands else "k_axpy_dot"
+            prob.profile_reset()
+            prob.profile_enable(1 << bz._lib.KERNEL_CATEGORIES.index(dom), period=int(os.environ.get("BZ_BENCH_PERIOD", "8")))
+            st0 = prob.panoc_stats()
+        except Exception as e:      # noqa: BLE001
+            ok, err = 0, repr(e)[:300]
+        ok = sync(ok)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            prob.panoc_step()
-        barrier()
+        if ok:
+            try:
+                for _ in range(steps):
+                    prob.panoc_step()
+            except Exception as e:      # noqa: BLE001
+                ok, err = 0, repr(e)[:300]
+        ok = sync(ok)
         elapsed = time.perf_counter() - t0
-        prob.profile_enable(False)
         if grp is not None:
             elapsed = grp.reduce(elapsed, max)
+        if not ok:
+            return {"failed": err or "another rank failed"}
+        prob.profile_enable(False)
         return {"elapsed": elapsed, "st0": st0, "st1": prob.panoc_stats(), "sc": prob.panoc_scalars(),
                 "prof": prob.profile(), "prof_warm": prof_warm, "dom": dom}
 
     prob = make_problem(ctx)
     R = timed_run(prob, args.steps, args.warmup)
+    if "failed" in R and transport == "p2p" and ctx_rccl is not None:
+        # every rank sees the same verdict (sync carries it): fall back to the RCCL transport together
+        p2p_note = f"p2p failed in the timed run ({R['failed']}); RCCL timed instead"
+        print(f"[bench] rank {rank}: {p2p_note}", file=sys.stderr, flush=True)
+        ctx, transport = ctx_rccl, "rccl"
+        prob = make_problem(ctx)
+        R = timed_run(prob, args.steps, args.warmup)
+    if "failed" in R:
+        raise SystemExit(f"[bench] rank {rank}: timed run failed: {R['failed']}")
     prob.close()
     elapsed, st0, st1, sc, prof_all, prof_warm, dom = (R[k] for k in ("elapsed", "st0", "st1", "sc", "prof", "prof_warm", "dom"))
 
@@ -501,7 +565,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else
                        f"x sharded over {world} GPUs, scalars exchanged by " +
                        ("peer-to-peer mailboxes over xGMI" if transport == "p2p" else "RCCL all-gather"),
-                       "scalar_transport": transport, "p2p_note": p2p_note,
+                       "scalar_transport": transport, "p2p_note": p2p_note, "rccl_note": rccl_note,
                        "lbfgs_form": "compact representation: one pass and one reduction phase per iteration" if compact
                        else "two-loop recursion (persistent kernel, 2M-1 grid phases)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -532,6 +596,8 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     ctx.close()
+    if ctx_rccl is not None and ctx_rccl is not ctx:
+        ctx_rccl.close()
     if grp is not None:
         grp.barrier()
         grp.close()

@@ -95,3 +95,32 @@ def test_two_ranks_on_one_gpu_match_single_rank(bz, persist, compact):
         assert all(r[6] == 0 and ITERS <= r[7] <= 2 * ITERS + 12 for r in res)   # ~1 exchange per iteration
     else:
         assert all(r[6] == 0 and r[7] > 5 * ITERS for r in res)
+
+
+@pytest.mark.gpu
+def test_bench_launcher_two_ranks_share_one_gpu():
+    """The driver's N > 1 launch line (torch.distributed.run, one process per rank) end to end on a one-GPU
+    box: both ranks on device 0, x sharded, p2p mailboxes through HIP IPC, TCP rendezvous, max-over-ranks
+    timing, one JSON line from rank 0.  RCCL refuses two ranks on one device, hence --no-rccl (the p2p
+    scalars are then checked for rank agreement instead of against RCCL)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BZ_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40",
+           "--warmup", "10", "--n", "2e6", "--no-rccl"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["scalar_transport"] == "p2p" and d["config"]["n_per_gpu"] * 2 >= 2_000_000
+    assert d["roofline"]["kernel"].startswith("bz::k_fused_compact") and d["cpu_baseline"] is None
+    assert d["solver"]["fused_iterations"] >= 38

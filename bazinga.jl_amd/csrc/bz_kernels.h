@@ -1656,7 +1656,7 @@ __device__ __forceinline__ void compact_coefs(const CompactCoef<MM>& C, T (&u1)[
 
 // d for one pack:  d = H0 v + sum u1_i s_i + sum (H0 u2_i) y_i ,  v = -res
 template <class T, int MM>
-__device__ __forceinline__ void compact_d(const CompactVecs<T, MM>& V, T H0, const T (&u1)[MM],
+__device__ __forceinline__ void compact_d(int m, T H0, const T (&u1)[MM],
                                           const T (&u2h)[MM], const Pack<T>& pres, const Pack<T> (&ps)[MM],
                                           const Pack<T> (&py)[MM], Pack<T>& d) {
 #pragma unroll
@@ -1664,10 +1664,10 @@ __device__ __forceinline__ void compact_d(const CompactVecs<T, MM>& V, T H0, con
         T a = H0 * (T(-1) * pres.v[e]);
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < V.m) { T t = u1[i] * ps[i].v[e]; a = a + t; }
+            if (i < m) { T t = u1[i] * ps[i].v[e]; a = a + t; }
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < V.m) { T t = u2h[i] * py[i].v[e]; a = a + t; }
+            if (i < m) { T t = u2h[i] * py[i].v[e]; a = a + t; }
         d.v[e] = a;
     }
 }
@@ -1686,7 +1686,7 @@ k_compact_xd(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ res,
 #pragma unroll
         for (int i = 0; i < MM; ++i)
             if (i < V.m) { ps[i] = ld(V.S[i], i0, cnt); py[i] = ld(V.Y[i], i0, cnt); }
-        compact_d<T, MM>(V, H0, u1, u2h, pres, ps, py, d);
+        compact_d<T, MM>(V.m, H0, u1, u2h, pres, ps, py, d);
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) o.v[e] = px.v[e] + d.v[e];
         st(x_d, i0, cnt, o);
@@ -1727,16 +1727,30 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
 //           + 10 + 2MM + i: <s_i, -res> ; + 10 + 3MM + i: <y_i, -res> ; then <s_new, -res>, <y_new, -res>
 //           with res the NEW residual: the p and w of the next application, whichever pairs it keeps —
 //           so the whole iteration is this one pass (S and Y are in registers here anyway)
-template <class T, int MM, bool NT>
+template <class T, int MM, bool NT, bool SPEC>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
                 T* __restrict__ z, T* __restrict__ res, T* __restrict__ s_new, T* __restrict__ y_new,
                 int64_t n, double* __restrict__ parts, int slot0) {
+    // SPEC: the headline family (cfg 2 / cfg 5) with everything uniform known at compile time — f =
+    // DiagQuadratic, g = NormL1, D = Box with scalar bounds, full memory: no kind switches, no optional
+    // streams, far fewer live scalar registers (the generic body spills ~300 SGPRs to VGPR lanes)
+    const int fk = SPEC ? (int)BZ_F_DIAG_QUADRATIC : P.f_kind;
+    const int gk = SPEC ? (int)BZ_G_NORM_L1 : P.g_kind;
+    const int dk = SPEC ? (int)BZ_D_BOX : P.D_kind;
+    const int m = SPEC ? MM : V.m;
     T u1[MM], u2h[MM];
     compact_coefs<T, MM>(C, u1, u2h);
-    const T H0 = (T)C.H0;
-    const T gl = gamma * P.g_lambda;
+    T H0 = (T)C.H0;
+    T gl = gamma * P.g_lambda;
+    if (SPEC) {      // keep the per-application coefficients in vector registers: scalar ones are the scarce kind here
+#pragma unroll
+        for (int i = 0; i < MM; ++i) { asm volatile("" : "+v"(u1[i])); asm volatile("" : "+v"(u2h[i])); }
+        asm volatile("" : "+v"(H0));
+        asm volatile("" : "+v"(gl));
+        asm volatile("" : "+v"(gamma));
+    }
     constexpr int NS = 10 + 4 * MM + 2;
     double acc[NS];
 #pragma unroll
@@ -1744,24 +1758,31 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
-        load_params<T, NT>(P, i0, cnt, L, true, true, true);
+        if (SPEC) {
+            L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
+            L.mu = ldp<T, NT>(P.mu, i0, cnt); L.muy = ldp<T, NT>(P.muy, i0, cnt);
+            L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
+            L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
+        } else {
+            load_params<T, NT>(P, i0, cnt, L, true, true, true);
+        }
         Pack<T> px = ldp<T, NT>(x, i0, cnt), prp = ldp<T, NT>(res_prev, i0, cnt), ps[MM], py[MM], d;
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < V.m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
-        compact_d<T, MM>(V, H0, u1, u2h, prp, ps, py, d);
+            if (i < m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
+        compact_d<T, MM>(m, H0, u1, u2h, prp, ps, py, d);
         Pack<T> pxd, pz, pr, pss, pyy;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
             T xd = px.v[e] + d.v[e];
-            ALOut<T> o1 = al_elem(P.f_kind, P.D_kind, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
+            ALOut<T> o1 = al_elem(fk, dk, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
                                   L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
             T t = gamma * o1.grad;
             T y = xd - t;
             T gterm;
-            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            T zz = prox_elem(gk, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
             T r = xd - zz;
-            ALOut<T> o2 = al_elem(P.f_kind, P.D_kind, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
+            ALOut<T> o2 = al_elem(fk, dk, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
                                   L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
             T sv = xd - px.v[e];
             T yy = r - prp.v[e];
@@ -1782,14 +1803,14 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                 acc[9] = nanmax(acc[9], (double)(w < T(0) ? -w : w));
 #pragma unroll
                 for (int i = 0; i < MM; ++i)
-                    if (i < V.m) {
+                    if (i < m) {
                         acc[10 + i] += (double)(ps[i].v[e] * yy);
                         acc[10 + MM + i] += (double)(py[i].v[e] * yy);
                     }
                 const T nr = T(-1) * r;
 #pragma unroll
                 for (int i = 0; i < MM; ++i)
-                    if (i < V.m) {
+                    if (i < m) {
                         acc[10 + 2 * MM + i] += (double)(ps[i].v[e] * nr);
                         acc[10 + 3 * MM + i] += (double)(py[i].v[e] * nr);
                     }

@@ -1275,12 +1275,18 @@ template <class T> class Solver final : public SolverBase {
             // at n = 10^7, -9 % at n = 1.25*10^6 where the 21 vectors fit)
             static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
             const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * (2 * CM + 11) > 600e6;
-            if (nt)
-                launch(C_FUSED, k_fused_compact<T, CM, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
-                       gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
-            else
-                launch(C_FUSED, k_fused_compact<T, CM, false>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
-                       gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
+            // headline family with everything uniform fixed at compile time (see the kernel)
+            static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
+            const bool spec = spec_env && desc.f_kind == BZ_F_DIAG_QUADRATIC && desc.g_kind == BZ_G_NORM_L1 &&
+                              desc.D_kind == BZ_D_BOX && !P.D_lo_vec && !P.D_hi_vec && CV.m == CM;
+#define BZ_LAUNCH_FC(NT_, SPEC_)                                                                                  \
+    launch(C_FUSED, k_fused_compact<T, CM, NT_, SPEC_>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
+           gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
+            if (nt && spec) BZ_LAUNCH_FC(true, true);
+            else if (nt) BZ_LAUNCH_FC(true, false);
+            else if (spec) BZ_LAUNCH_FC(false, true);
+            else BZ_LAUNCH_FC(false, false);
+#undef BZ_LAUNCH_FC
             if (ctx->p2p_on) {
                 // exchange + fold over the ranks + read-back in one launch (no k_collect)
                 tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);

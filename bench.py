@@ -280,7 +280,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=float, default=1e7, help="global problem size (default: BASELINE cfg 2)")
+    ap.add_argument("--n", "--size", dest="n", type=float, default=1e7,
+                    help="global problem size (default: BASELINE cfg 2); spell it --size under torch.distributed.run, "
+                         "whose own parser claims --n as an abbreviation")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 (default, the headline metric); cfg3 2048^2 stencil QP; cfg4 dense-A basis "
                          "pursuit fp32; cfg5 = cfg2 at n=1e8")

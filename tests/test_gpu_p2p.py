@@ -114,7 +114,7 @@ def test_bench_launcher_two_ranks_share_one_gpu():
     env = dict(os.environ, BZ_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40",
-           "--warmup", "10", "--n", "2e6", "--no-rccl"]
+           "--warmup", "10", "--size", "2e6", "--no-rccl"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

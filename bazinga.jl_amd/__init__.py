@@ -8,7 +8,8 @@ from ._lib import BazingaHipError
 from .device import Context, Problem, default_context, set_default_context, shard_bounds
 from .oracles import (ClosedSet, DenseAffine, DiagQuadratic, FreeSet, IdentityFunction, IndBox, IndFree, IndicatorSet,
                       LeastSquares, NormL0Box, NormLpPowerBox, NormLpPowerNonneg, Quadratic,
-                      NormL1, NormL1Box, NormL1Nonneg, Stencil5ptQuadratic, UnsupportedOracle, Zero, ZeroSet)
+                      NormL1, NormL1Box, NormL1Nonneg, Stencil5ptQuadratic, UnsupportedOracle, Zero, ZeroSet,
+                      PairwiseSet, VanishingConstraintPairs, ComplementarityPairs, EitherOrPairs, XorPairs)
 from .solvers import (LBFGS, NoAcceleration, AugLagFun, AugLagFunSlack, AugLagUpdate, NonsmoothCostFun, NonsmoothCostFunSlack,
                       PANOCplus, alps, als,
                       default_dual_safeguard, default_penalty_parameter, default_subsolver)

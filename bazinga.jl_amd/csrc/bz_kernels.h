@@ -231,10 +231,45 @@ __device__ __forceinline__ void bz_for_chunks(int64_t n, F&& f) {
 // ---------------------------------------------------------------------------
 // element-wise oracle arithmetic (mirrors oracle/bazinga_ref.py and oracle/c)
 // ---------------------------------------------------------------------------
-template <class T> __device__ __forceinline__ T proj_D(int kind, T t, T lo, T hi) {
+// max(0, x) / min(0, x) as Julia's: NaN propagates, and the zero returned for x = -0.0 / +0.0 is the literal's
+template <class T> __device__ __forceinline__ T max0(T x) { return (x > T(0) || x != x) ? x : T(0); }
+template <class T> __device__ __forceinline__ T min0(T x) { return (x < T(0) || x != x) ? x : T(0); }
+
+// The pairwise sets: this element's component of the projection of the pair (x1, x2); `pos` says which
+// component this element is (0: x1 = t, x2 = tp ; 1: x1 = tp, x2 = t).
+template <class T> __device__ __forceinline__ T proj_pair(int kind, T t, T tp, int pos) {
+    const T x1 = pos ? tp : t, x2 = pos ? t : tp;
+    T z1, z2;
+    if (kind == BZ_D_VC_PAIRS) {              // vanishingConstraints.jl:27-46  (x1 >= 0, x1*x2 >= 0)
+        z1 = T(0); z2 = T(0);
+        if (x1 <= T(0)) { z2 = x2; }
+        else if (x2 >= T(0)) { z1 = x1; z2 = x2; }
+        else if (x1 + x2 > T(0)) { z1 = x1; }
+        else { z2 = x2; }                     // x1 + x2 < 0, and the set-valued tie x1 + x2 = 0
+    } else if (kind == BZ_D_CC_PAIRS) {       // complementarityConstraints.jl:8-20
+        if (x1 > T(0) && x2 > T(0)) {
+            z1 = x1; z2 = x2;
+            if (x2 > x1) z1 = T(0); else z2 = T(0);
+        } else { z1 = max0(x1); z2 = max0(x2); }
+    } else if (kind == BZ_D_EITHEROR_PAIRS) { // orConstraints.jl:7-17
+        z1 = x1; z2 = x2;
+        if (x1 < T(0) && x2 < T(0)) { if (x1 > x2) z1 = T(0); else z2 = T(0); }
+    } else {                                  // XOR, orConstraints.jl:24-36
+        z1 = x1; z2 = x2;
+        if (x1 * x2 > T(0)) {
+            if (x1 > x2) { z1 = max0(x1); z2 = min0(x2); }
+            else { z1 = min0(x1); z2 = max0(x2); }
+        }
+    }
+    return pos ? z2 : z1;
+}
+
+// tp / pos: the pair partner's argument and this element's position, used by the pairwise kinds only
+template <class T> __device__ __forceinline__ T proj_D(int kind, T t, T lo, T hi, T tp = T(0), int pos = 0) {
     // src/projections/{zeroSet,freeSet,indicatorSet}.jl
     if (kind == BZ_D_ZERO) return T(0);
     if (kind == BZ_D_FREE) return t;
+    if (kind >= BZ_D_VC_PAIRS) return proj_pair(kind, t, tp, pos);
     return t < lo ? lo : (t > hi ? hi : t);   // IndBox prox: if x<lb lb elseif x>ub ub else x
 }
 
@@ -246,11 +281,11 @@ template <class T> struct ALOut {
 // c = Identity and an element-wise f.
 template <class T>
 __device__ __forceinline__ ALOut<T> al_elem(int f_kind, int D_kind, T x, T q, T b, T mu, T muy,
-                                            T lo, T hi) {
+                                            T lo, T hi, T tp = T(0), int pos = 0) {
     ALOut<T> o;
     T cx = x;                       // eval!(cx, c, x)
     T t = cx + muy;                 // yupd = cx + mu*y
-    T s = proj_D(D_kind, t, lo, hi);
+    T s = proj_D(D_kind, t, lo, hi, tp, pos);
     t = t - s;                      // yupd -= s
     o.pterm = (t * t) / mu;         // (yupd^2)/mu, summed then halved
     T yupd = t / mu;                // yupd /= mu
@@ -484,7 +519,7 @@ k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, in
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
             ALOut<T> o = al_elem(fk, P.D_kind, px.v[e], L.q.v[e], L.b.v[e], L.mu.v[e],
-                                 L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+                                 L.muy.v[e], L.dlo.v[e], L.dhi.v[e], px.v[e ^ 1] + L.muy.v[e ^ 1], e & 1);
             if (fext == 1) {
                 o.grad = pe.v[e] + o.grad;                   // dfx + yupd  (al_elem returned 0 + yupd)
             } else if (fext == 2) {
@@ -1924,7 +1959,7 @@ k_dual_update(const T* __restrict__ cx, ElemParams<T> P, T* __restrict__ y, T* _
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
             T t = pc.v[e] + L.muy.v[e];
-            T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e]);
+            T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e], pc.v[e ^ 1] + L.muy.v[e ^ 1], e & 1);
             t = t - sv;
             t = t / L.mu.v[e];
             py.v[e] = t; ps.v[e] = sv;
@@ -1950,7 +1985,7 @@ k_penalty_init(const T* __restrict__ cx, ElemParams<T> P, double denom, T* __res
         Pack<T> dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
-            T sv = proj_D(P.D_kind, pc.v[e], dlo.v[e], dhi.v[e]);
+            T sv = proj_D(P.D_kind, pc.v[e], dlo.v[e], dhi.v[e], pc.v[e ^ 1], e & 1);
             T d = pc.v[e] - sv;
             double d2 = (double)(d * d);
             double h = 0.5 * d2;

@@ -131,7 +131,13 @@ template <class T> class Solver final : public SolverBase {
         }
         if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_NORM_LP_BOX)
             throw Error(BZ_ERR_ARG, "unknown g kind");
-        if (d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_BOX) throw Error(BZ_ERR_ARG, "unknown D kind");
+        if (d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_XOR_PAIRS) throw Error(BZ_ERR_ARG, "unknown D kind");
+        if (d.D_kind >= BZ_D_VC_PAIRS) {
+            // adjacent pairs live inside one 16-byte pack: only the element-wise kernels (c = Identity) see them
+            if (d.c_kind != BZ_C_IDENTITY || slack || d.f_kind == BZ_F_STENCIL5)
+                throw Error(BZ_ERR_UNSUPPORTED, "pairwise D sets need c = Identity, an element-wise or dense f and no slack");
+            if (ny % 2 != 0) throw Error(BZ_ERR_ARG, "pairwise D sets need an even number of constraints");
+        }
         if ((d.g_kind == BZ_G_NORM_L1 || d.g_kind == BZ_G_NORM_L1_NONNEG ||
              d.g_kind == BZ_G_NORM_L1_BOX || d.g_kind == BZ_G_NORM_L0_BOX) && d.g_lambda < 0)
             throw Error(BZ_ERR_ARG, "parameter lambda must be nonnegative");
@@ -1150,7 +1156,7 @@ template <class T> class Solver final : public SolverBase {
         if (o.lbfgs_compact && M > CM) throw Error(BZ_ERR_ARG, "lbfgs_compact supports lbfgs_memory <= 5");
         compact_ok = o.lbfgs_compact && M >= 1;
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
-        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack &&
+        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack && desc.D_kind <= BZ_D_BOX &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread

@@ -202,6 +202,36 @@ def ClosedSet(f):
     return IndicatorSet(f)
 
 
+class PairwiseSet(ClosedSetBase):
+    """D = product of a 2-element set over the ADJACENT pairs (c(x)[2j], c(x)[2j+1]) — how demo/mpvca.jl:
+    105-106,147-148 and demo/eitheror.jl:79-88,123-130 build their sets from the package's 2-element
+    projections.  kind: "vc" (project_onto_VC_set!, vanishingConstraints.jl:27-46), "cc"
+    (project_onto_CC_set!, complementarityConstraints.jl:8-20), "eitheror" / "xor"
+    (orConstraints.jl:7-17 / 24-36)."""
+    KINDS = ("vc", "cc", "eitheror", "xor")
+
+    def __init__(self, kind):
+        if kind not in self.KINDS:
+            raise ValueError(f"kind must be one of {self.KINDS}")
+        self.kind = kind
+
+
+def VanishingConstraintPairs():
+    return PairwiseSet("vc")
+
+
+def ComplementarityPairs():
+    return PairwiseSet("cc")
+
+
+def EitherOrPairs():
+    return PairwiseSet("eitheror")
+
+
+def XorPairs():
+    return PairwiseSet("xor")
+
+
 # ------------------------------------------------------------------ lowering
 def _vec(a, dtype, n, name):
     v = np.ascontiguousarray(a, dtype=dtype)
@@ -317,6 +347,11 @@ def lower(f, g, c, D, n, ny, dtype, slack=False):
             d.D_hi_vec = ptr(_vec(D.f.ub, dtype, ny, "ub"))
     elif isinstance(D, IndicatorSet) and isinstance(D.f, IndFree):
         d.D_kind = L.BZ_D_FREE
+    elif isinstance(D, PairwiseSet):
+        d.D_kind = {"vc": L.BZ_D_VC_PAIRS, "cc": L.BZ_D_CC_PAIRS, "eitheror": L.BZ_D_EITHEROR_PAIRS,
+                    "xor": L.BZ_D_XOR_PAIRS}[D.kind]
+        if ny % 2:
+            raise ValueError("pairwise sets need an even number of constraints")
     else:
         raise UnsupportedOracle(f"D of type {type(D).__name__} is not lowered to the device")
     return d, keep

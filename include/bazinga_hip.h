@@ -70,6 +70,12 @@ extern "C" {
 #define BZ_D_ZERO            0   /* src/projections/zeroSet.jl:17-20                  */
 #define BZ_D_FREE            1   /* src/projections/freeSet.jl:17-20                  */
 #define BZ_D_BOX             2   /* ClosedSet(IndBox(lo,hi)), indicatorSet.jl:8-11    */
+/* pairwise sets over ADJACENT pairs (cx[2j], cx[2j+1]), ny even — the layout of demo/mpvca.jl:105-106,147-148
+ * and demo/eitheror.jl:79-88,123-130; c = Identity, no slack.  The 2-element projections they apply:      */
+#define BZ_D_VC_PAIRS        3   /* project_onto_VC_set!       src/projections/vanishingConstraints.jl:27-46   */
+#define BZ_D_CC_PAIRS        4   /* project_onto_CC_set!       src/projections/complementarityConstraints.jl:8-20 */
+#define BZ_D_EITHEROR_PAIRS  5   /* project_onto_EITHEROR_set! src/projections/orConstraints.jl:7-17           */
+#define BZ_D_XOR_PAIRS       6   /* project_onto_XOR_set!      src/projections/orConstraints.jl:24-36          */
 
 typedef struct bz_ctx     bz_ctx;
 typedef struct bz_problem bz_problem;

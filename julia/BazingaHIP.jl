@@ -99,6 +99,24 @@ lower_D!(d, D::Bazinga.ZeroSet) = (d.D_kind = 0)
 lower_D!(d, D::Bazinga.FreeSet) = (d.D_kind = 1)
 lower_D!(d, D::Bazinga.IndicatorSet{<:ProximalOperators.IndBox{<:Real,<:Real}}) =
     (d.D_kind = 2; d.D_lo = D.f.lb; d.D_hi = D.f.ub)
+"""
+    PairwiseSet(kind)   kind in (:vc, :cc, :eitheror, :xor)
+
+The package's 2-element projections (`project_onto_VC_set!` etc.) applied to every adjacent pair
+`(cx[2j-1], cx[2j])`, the way `demo/mpvca.jl:103-107` and `demo/eitheror.jl:121-131` define their sets.
+"""
+struct PairwiseSet <: Bazinga.ClosedSet
+    kind::Symbol
+end
+function Bazinga.proj!(z, D::PairwiseSet, x)
+    p! = D.kind === :vc ? Bazinga.project_onto_VC_set! : D.kind === :cc ? Bazinga.project_onto_CC_set! :
+         D.kind === :eitheror ? Bazinga.project_onto_EITHEROR_set! : Bazinga.project_onto_XOR_set!
+    for j in 1:2:length(x)
+        p!(@view(z[j:j+1]), x[j:j+1])
+    end
+    return nothing
+end
+lower_D!(d, D::PairwiseSet) = (d.D_kind = Dict(:vc => 3, :cc => 4, :eitheror => 5, :xor => 6)[D.kind])
 lower_D!(d, D) = error("BazingaHIP: D of type $(typeof(D)) is not lowered to the device")
 
 mutable struct Problem

@@ -145,6 +145,66 @@ def project_onto_EITHEROR_set(z, x):
     return None
 
 
+def project_onto_XOR_set(z, x):
+    """src/projections/orConstraints.jl:24-36"""
+    z[...] = x
+    if x[0] * x[1] > 0:
+        if x[0] > x[1]:
+            z[0] = max(0, x[0])
+            z[1] = min(0, x[1])
+        else:
+            z[0] = min(0, x[0])
+            z[1] = max(0, x[1])
+    return None
+
+
+def project_onto_VC_set(z, x):
+    """src/projections/vanishingConstraints.jl:27-46"""
+    z[...] = 0
+    if x[0] <= 0:
+        z[1] = x[1]
+    else:
+        if x[1] >= 0:
+            z[...] = x
+        else:
+            if x[0] + x[1] > 0:
+                z[0] = x[0]
+            elif x[0] + x[1] < 0:
+                z[1] = x[1]
+            else:               # set-valued case
+                z[1] = x[1]
+    return None
+
+
+def project_onto_CC_set(z, x):
+    """src/projections/complementarityConstraints.jl:8-20"""
+    if x[0] > 0 and x[1] > 0:
+        z[...] = x
+        if x[1] > x[0]:
+            z[0] = 0
+        else:
+            z[1] = 0
+    else:
+        z[...] = np.maximum(0, x)
+    return None
+
+
+class PairwiseSet:
+    """D as the demos build it from the 2-element projections: the same set over every ADJACENT pair
+    (demo/mpvca.jl:105-106,147-148 ; demo/eitheror.jl:79-88,123-130)."""
+    _P = {"vc": project_onto_VC_set, "cc": project_onto_CC_set, "eitheror": project_onto_EITHEROR_set,
+          "xor": project_onto_XOR_set}
+
+    def __init__(self, kind):
+        self.kind = kind
+        self._proj = self._P[kind]
+
+    def proj(self, z, x):
+        for j in range(0, x.shape[0], 2):
+            self._proj(z[j:j + 2], x[j:j + 2])
+        return None
+
+
 class SetRosenbrock:
     """demo/rosenbrock.jl:76-80"""
 

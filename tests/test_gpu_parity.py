@@ -804,3 +804,56 @@ def test_compact_lbfgs_alps(bz, ref):
     assert a[5] == o[5] == "first_order" and a[2] == o[2]
     assert abs(a[3] - o[3]) <= max(3, 0.05 * o[3])
     assert rel(a[0], o[0]) <= 1e-8
+
+
+def make_pairs(bz, ref, n, kind, g="zero"):
+    d = bz.synth.l1_quadratic(n)
+    g_d, g_r = (bz.NormL1(0.3), ref.NormL1(0.3)) if g == "l1" else (bz.Zero(), ref.Zero())
+    # shift b so that the unconstrained minimiser b/q has both signs in both slots of a pair
+    return ((bz.DiagQuadratic(d["q"], 0.2 * d["b"]), g_d, bz.IdentityFunction(), bz.PairwiseSet(kind)),
+            (ref.DiagQuadratic(d["q"], 0.2 * d["b"]), g_r, ref.IdentityFunction(), ref.PairwiseSet(kind)))
+
+
+@pytest.mark.parametrize("kind", ["vc", "cc", "eitheror", "xor"])
+@pytest.mark.parametrize("n", [2, 6, 1000, 262146])
+def test_pairwise_sets_al_gradient_bit_exact(bz, ref, n, kind):
+    """SURVEY f-2: D built from the 2-element projections over adjacent pairs (vanishingConstraints.jl:27-46,
+    complementarityConstraints.jl:8-20, orConstraints.jl:7-36).  gradient!(dlx, al, x) element-wise
+    bit-exact against the oracle, including ties, zeros of either sign and points on the sets' boundaries."""
+    dev, orc = make_pairs(bz, ref, n, kind)
+    rng = np.random.default_rng(n + len(kind))
+    x = rng.standard_normal(n)
+    mu = 10.0 ** rng.uniform(-2, 1, n)
+    y = rng.standard_normal(n)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5])
+    k = min(n, 240)
+    x[:k] = special[rng.integers(0, 6, k)]
+    y[:k] = 0.0                                   # c(x) + mu*y = x exactly: the special values reach the projection
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x)
+    g_ref = np.empty(n)
+    lx = al.gradient(g_ref, x)
+    assert np.array_equal(g_dev, g_ref)
+    assert abs(vals[0] - lx) <= 1e-13 * max(1.0, abs(lx))
+    prob.close()
+
+
+@pytest.mark.parametrize("kind,g", [("vc", "zero"), ("cc", "l1"), ("eitheror", "zero"), ("xor", "l1")])
+def test_pairwise_sets_alps(bz, ref, kind, g):
+    """Whole ALPS solves with a pairwise (nonconvex) D: same outer/inner counts and solution as the oracle,
+    and the returned c(x) = x lies in the set to tol_prim."""
+    n = 2000
+    dev, orc = make_pairs(bz, ref, n, kind, g)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    o = ref.alps(*orc, x0, y0)
+    a = bz.alps(*dev, x0, y0)
+    assert a[5] == o[5]
+    assert a[2] == o[2] and abs(a[3] - o[3]) <= max(2, 0.02 * o[3])
+    assert rel(a[0], o[0]) <= 1e-8
+    z = np.empty(n)
+    orc[3].proj(z, a[0])
+    assert np.max(np.abs(z - a[0])) <= 1e-5
+    with pytest.raises(Exception):
+        bz.Problem(dev[0], dev[1], dev[2], bz.PairwiseSet(kind), n - 1, n - 1, np.float64)      # odd ny

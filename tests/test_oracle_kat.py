@@ -179,3 +179,38 @@ def test_als_rosenbrock_and_agrees_with_alps():
         e = np.zeros(2 * m)
         e[i] = 1e-6
         assert abs((F(xs + e) - F(xs - e)) / 2e-6 - g[i]) <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["vc", "cc", "eitheror", "xor"])
+def test_pairwise_projections_are_nearest_points(kind):
+    """The reference ships no test for its 2-element projections (vanishingConstraints.jl:27-46,
+    complementarityConstraints.jl:8-20, orConstraints.jl:7-36): pin the restatement by what a projection
+    is.  Each set is a union of two convex pieces; the result must lie in the set, be idempotent and be as
+    close as the nearer of the two piece projections — on random points, axis points, ties and zeros."""
+    def max0(v): return v if v > 0 else 0.0
+    def min0(v): return v if v < 0 else 0.0
+    pieces = {"vc": (lambda a, b: (0.0, b), lambda a, b: (max0(a), max0(b))),
+              "cc": (lambda a, b: (0.0, max0(b)), lambda a, b: (max0(a), 0.0)),
+              "eitheror": (lambda a, b: (max0(a), b), lambda a, b: (a, max0(b))),
+              "xor": (lambda a, b: (max0(a), min0(b)), lambda a, b: (min0(a), max0(b)))}[kind]
+    member = {"vc": lambda a, b: a >= 0 and a * b >= 0,
+              "cc": lambda a, b: a >= 0 and b >= 0 and a * b == 0,
+              "eitheror": lambda a, b: a >= 0 or b >= 0,
+              "xor": lambda a, b: (a >= 0 and b <= 0) or (a <= 0 and b >= 0)}[kind]
+    rng = np.random.default_rng(11)
+    pts = [tuple(p) for p in rng.standard_normal((400, 2)) * 2]
+    special = [-2.0, -1.0, -0.0, 0.0, 1.0, 2.0]
+    pts += [(a, b) for a in special for b in special] + [(1.5, -1.5), (-1.5, 1.5), (0.3, -0.7), (0.7, -0.3)]
+    D = R.PairwiseSet(kind)
+    x = np.array(pts).reshape(-1)
+    z = np.empty_like(x)
+    D.proj(z, x)
+    z2 = np.empty_like(x)
+    D.proj(z2, z)
+    assert np.array_equal(z, z2)                                   # idempotent
+    for j, (a, b) in enumerate(pts):
+        za, zb = z[2 * j], z[2 * j + 1]
+        assert member(za, zb), (kind, a, b, za, zb)
+        d = np.hypot(za - a, zb - b)
+        best = min(np.hypot(p[0] - a, p[1] - b) for p in (f(a, b) for f in pieces))
+        assert d <= best + 1e-15, (kind, a, b, za, zb)

@@ -721,11 +721,15 @@ def test_stencil_fast_path_equals_generic_bitwise(bz, ref):
         assert s1[key] == s2[key], key
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_randomised_kinds_alps_parity(bz, ref, seed):
+@pytest.mark.parametrize("seed,form", [(s, "two-loop") for s in range(12)] + [(s, "compact") for s in range(12)])
+def test_randomised_kinds_alps_parity(bz, ref, seed, form):
     """Seeded sweep over the lowered oracle kinds and ragged sizes: the device ALPS and the oracle ALPS take
-    the same outer/inner iteration counts (up to a late branch flip) and return the same point."""
+    the same outer/inner iteration counts (up to a late branch flip) and return the same point.  Both
+    evaluations of the L-BFGS operator, each against the oracle restated in the same form: the sweep walks
+    through tau backtracks, gamma halvings (memory reset), skipped pairs and growing memory, i.e. every way
+    the compact path can lose and regain the p, w it carries from one fused pass to the next."""
     rng = np.random.default_rng(1000 + seed)
+    compact = form == "compact"
     n = int(rng.integers(1, 6000))
     q = rng.uniform(0.2, 5.0, n)
     b = rng.standard_normal(n) * 4
@@ -748,9 +752,11 @@ def test_randomised_kinds_alps_parity(bz, ref, seed):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        o = ref.alps(f_r, g_r, ref.IdentityFunction(), D_r, x0, y0, maxit=40)
-    a = bz.alps(f_d, g_d, bz.IdentityFunction(), D_d, x0, y0, maxit=40)
-    tag = f"n={n} f={fk} g={gk} D={Dk}"
+        o = ref.alps(f_r, g_r, ref.IdentityFunction(), D_r, x0, y0, maxit=40,
+                     subsolver=lambda **kw: ref.PANOCplus(directions=ref.LBFGS(5, compact=compact), **kw))
+    a = bz.alps(f_d, g_d, bz.IdentityFunction(), D_d, x0, y0, maxit=40,
+                subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(5, compact=compact), **kw), resident=True)
+    tag = f"n={n} f={fk} g={gk} D={Dk} {form}"
     assert a[5] == o[5], tag
     assert a[2] == o[2], tag
     # Subproblems that need ~1000 inner iterations are sensitive to the rounding of the reduced scalars:

@@ -161,9 +161,14 @@ typedef struct {
                                 and is long enough; 0: one kernel per two-loop step.
                                 Same arithmetic, different (fixed) summation tree.       */
     int32_t lbfgs_compact;   /* 1: evaluate the SAME L-BFGS operator in its compact
-                                (Byrd-Nocedal-Schnabel) form: one reduction phase per
-                                application instead of 2M sequential ones (M <= 5).  An
-                                alternate rounding of the two-loop; default 0.            */
+                                (Byrd-Nocedal-Schnabel) representation (M <= 5): no
+                                sequential reductions, so for c = Identity with an
+                                element-wise f the whole iteration is ONE streaming pass
+                                over 2M+11 vectors and one reduction phase (one cross-GPU
+                                exchange) instead of 2M+1.  An alternate rounding of the
+                                two-loop recursion (its iterates track the fp64 oracle as
+                                closely as the two-loop kernels' do); default 0 = the
+                                reference's operation order.                             */
     int32_t reserved;
 } bz_panoc_opts;
 

@@ -94,6 +94,7 @@ SIGNATURES = {
     "bz_panoc_solve": (C.c_int, [_vp, _P(PanocOpts), _vp, _vp, _P(PanocStats)]),
     "bz_panoc_begin": (C.c_int, [_vp, _P(PanocOpts), _vp]),
     "bz_panoc_step": (C.c_int, [_vp]),
+    "bz_panoc_steps": (C.c_int, [_vp, C.c_int64]),
     "bz_panoc_finish": (C.c_int, [_vp, _vp, _P(PanocStats)]),
     "bz_panoc_scalars": (C.c_int, [_vp, _P(C.c_double)]),
     "bz_panoc_vector": (C.c_int, [_vp, C.c_int32, _vp]),

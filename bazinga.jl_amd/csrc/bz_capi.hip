@@ -169,6 +169,13 @@ int bz_panoc_begin(bz_problem* p, const bz_panoc_opts* o, const void* x0) {
 int bz_panoc_step(bz_problem* p) {
     return guard([&] { need(p, "problem"); p->s->step(); });
 }
+int bz_panoc_steps(bz_problem* p, int64_t k) {
+    return guard([&] {
+        need(p, "problem");
+        if (k < 0) throw bz::Error(BZ_ERR_ARG, "k must be nonnegative");
+        for (int64_t i = 0; i < k; ++i) p->s->step();
+    });
+}
 int bz_panoc_finish(bz_problem* p, void* x_out, bz_panoc_stats* st) {
     return guard([&] { need(p, "problem"); p->s->finish(x_out, st); });
 }

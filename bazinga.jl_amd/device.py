@@ -131,6 +131,10 @@ class Problem:
     def panoc_step(self):
         L.check(L.load().bz_panoc_step(self._h))
 
+    def panoc_steps(self, k: int):
+        """k consecutive Base.iterate(iter, state) steps in one library call."""
+        L.check(L.load().bz_panoc_steps(self._h, int(k)))
+
     def panoc_finish(self):
         out = np.empty(self.n, self.dtype)
         st = L.PanocStats()

@@ -208,6 +208,9 @@ int bz_panoc_solve(bz_problem* p, const bz_panoc_opts* o, const void* x0,
  *   finish = copy out state.z + stats                                               */
 int bz_panoc_begin(bz_problem* p, const bz_panoc_opts* o, const void* x0);
 int bz_panoc_step(bz_problem* p);
+/* k consecutive steps in one call (the same as calling bz_panoc_step k times: the stopping
+ * criterion is the caller's to test, through bz_panoc_scalars)                          */
+int bz_panoc_steps(bz_problem* p, int64_t k);
 int bz_panoc_finish(bz_problem* p, void* x_out, bz_panoc_stats* stats);
 /* scalars of the current state: out[0..15] =
  *  {k, gamma, tau, f_x(AL value at x), g_z, <gradL(x),res>, ||res||^2, stop_norm,

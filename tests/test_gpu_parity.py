@@ -863,3 +863,25 @@ def test_pairwise_sets_alps(bz, ref, kind, g):
     assert np.max(np.abs(z - a[0])) <= 1e-5
     with pytest.raises(Exception):
         bz.Problem(dev[0], dev[1], dev[2], bz.PairwiseSet(kind), n - 1, n - 1, np.float64)      # odd ny
+
+
+@pytest.mark.parametrize("M", [1, 3, 5])
+def test_compact_lbfgs_float32_and_short_memory(bz, ref, M):
+    """The compact form with T = Float32 (coefficients are formed in double on the host and applied in
+    Float32) and with memories shorter than its capacity: ALPS converges to the oracle's point."""
+    n = 20000
+    d, dev, orc = make_cfg2(bz, ref, n, dtype=np.float32)
+    x0, y0 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    a = bz.alps(*dev, x0, y0, tol=np.float32(1e-4),
+                subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(M, compact=True), **kw), resident=True)
+    o = ref.alps(*orc, x0, y0, tol=np.float32(1e-4),
+                 subsolver=lambda **kw: ref.PANOCplus(directions=ref.LBFGS(M), **kw))
+    assert a[0].dtype == np.float32 and a[5] == o[5] == "first_order"
+    assert np.max(np.abs(a[0] - o[0])) <= 2e-3
+    assert abs(a[3] - o[3]) <= max(5, 0.2 * o[3])
+    d64, dev64, orc64 = make_cfg2(bz, ref, n)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    a = bz.alps(*dev64, x0, y0, subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(M, compact=True), **kw), resident=True)
+    o = ref.alps(*orc64, x0, y0, subsolver=lambda **kw: ref.PANOCplus(directions=ref.LBFGS(M, compact=True), **kw))
+    assert a[5] == o[5] == "first_order" and a[2] == o[2] and abs(a[3] - o[3]) <= max(3, 0.05 * o[3])
+    assert rel(a[0], o[0]) <= 1e-8

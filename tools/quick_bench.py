@@ -29,8 +29,11 @@ prob.panoc_begin(opts, np.zeros(n))
 for _ in range(20):
     prob.panoc_step()
 t0 = time.perf_counter()
-for _ in range(steps):
-    prob.panoc_step()
+if os.environ.get("QB_BULK") == "1":
+    prob.panoc_steps(steps)
+else:
+    for _ in range(steps):
+        prob.panoc_step()
 t1 = time.perf_counter()
 sc = prob.panoc_scalars(); st = prob.panoc_stats()
 its = steps / (t1 - t0)

@@ -218,6 +218,13 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y, const 
     });
 }
 
+int bz_problem_halo_export(bz_problem* p, void* handle64) {
+    return guard([&] { need(p, "problem"); need(handle64, "handle64"); p->s->halo_export(handle64); });
+}
+int bz_problem_halo_connect(bz_problem* p, const void* prev64, const void* next64) {
+    return guard([&] { need(p, "problem"); p->s->halo_connect(prev64, next64); });
+}
+
 int bz_profile_enable(bz_problem* p, int32_t on) {
     return guard([&] { need(p, "problem"); p->s->profile_enable((unsigned)on); });
 }

@@ -551,14 +551,21 @@ k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, in
 //   slots: +0 sum f terms, +1 sum t^2/mu.   f_only: skip the AL terms (alps.jl:39, f(x) alone).
 // ---------------------------------------------------------------------------
 // one pack of the stencil AL gradient; accF/accP accumulate the f and penalty terms of the valid lanes
+// Row-block sharding (x sharded over the GPUs by grid rows): the row above the first local row and the row
+// below the last one are the neighbour ranks' (k_halo_exchange); a null halo is the Dirichlet-0 boundary.
+template <class T> struct StencilHalo {
+    const T* north;      // ny values: the last row of the previous rank, or null
+    const T* south;      // ny values: the first row of the next rank, or null
+};
 template <class T>
 __device__ __forceinline__ Pack<T> stencil_al_pack(const T* __restrict__ x, const ElemParams<T>& P, int64_t nx,
                                                    int64_t ny, int f_only, int64_t i0, int cnt,
-                                                   const Pack<T>& xc, double& accF, double& accP) {
+                                                   const Pack<T>& xc, double& accF, double& accP,
+                                                   StencilHalo<T> halo = StencilHalo<T>{nullptr, nullptr}) {
     constexpr int N = PackN<T>::N;
     const int64_t i = i0 / ny, j0 = i0 - i * ny;
-    Pack<T> xn = (i > 0) ? ld(x, i0 - ny, cnt) : splat(T(0));
-    Pack<T> xs = (i + 1 < nx) ? ld(x, i0 + ny, cnt) : splat(T(0));
+    Pack<T> xn = (i > 0) ? ld(x, i0 - ny, cnt) : (halo.north ? ld(halo.north, j0, cnt) : splat(T(0)));
+    Pack<T> xs = (i + 1 < nx) ? ld(x, i0 + ny, cnt) : (halo.south ? ld(halo.south, j0, cnt) : splat(T(0)));
     const T west = (j0 > 0) ? x[i0 - 1] : T(0);
     const T east = (j0 + N < ny) ? x[i0 + N] : T(0);
     Pack<T> pb = ld(P.b, i0, cnt);
@@ -595,12 +602,12 @@ __device__ __forceinline__ Pack<T> stencil_al_pack(const T* __restrict__ x, cons
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_algrad_stencil(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, int f_only,
-                 T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0) {
+                 T* __restrict__ grad, int64_t n, double* __restrict__ parts, int slot0, StencilHalo<T> halo) {
     double acc[2] = {0.0, 0.0};
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> xc = ld(x, i0, cnt);
-        Pack<T> pg = stencil_al_pack(x, P, nx, ny, f_only, i0, cnt, xc, acc[0], acc[1]);
+        Pack<T> pg = stencil_al_pack(x, P, nx, ny, f_only, i0, cnt, xc, acc[0], acc[1], halo);
         if (grad) st(grad, i0, cnt, pg);
     });
     block_reduce_store<2>(acc, 0u, parts, slot0);
@@ -1029,6 +1036,49 @@ static __global__ void __launch_bounds__(XBLOCK) k_exchange_collect(XCollectArgs
         __threadfence_system();                       // value before ticket
         __hip_atomic_store(b.host_out + 2 * tid + 1, b.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// Halo exchange of the row-block-sharded stencil: this rank's first grid row goes to the previous rank's
+// "south" halo and its last row to the next rank's "north" halo, straight into the neighbours' HBM through
+// the IPC mapping (plain 16-byte stores), then a system-scope release and a sequence-number flag; then wait
+// for the two rows this rank is owed.  Double-buffered by the parity of the sequence number: a neighbour
+// can run at most one exchange ahead, because finishing an exchange needs this rank's flag of the same
+// number.  The halo region is fine-grained memory, so the consumer kernel's plain loads see the rows.
+template <class T> struct HaloArgs {
+    const T* first_row;          // ny values
+    const T* last_row;
+    T* prev_south;               // previous rank's south-halo row of this parity (null: no previous rank)
+    T* next_north;               // next rank's north-halo row of this parity (null: no next rank)
+    unsigned long long* prev_flag;   // the flag words this rank sets at its neighbours
+    unsigned long long* next_flag;
+    const unsigned long long* my_north_flag;   // the flag words its neighbours set here
+    const unsigned long long* my_south_flag;
+    unsigned long long seq;
+    int64_t ny;
+    int* timeout;
+};
+template <class T>
+__global__ void __launch_bounds__(XBLOCK) k_halo_exchange(HaloArgs<T> a) {
+    constexpr int N = PackN<T>::N;
+    const int64_t packs = a.ny / N;
+    for (int64_t c = threadIdx.x; c < packs; c += XBLOCK) {
+        if (a.prev_south) st(a.prev_south, c * N, N, ld(a.first_row, c * N, N));
+        if (a.next_north) st(a.next_north, c * N, N, ld(a.last_row, c * N, N));
+    }
+    __threadfence_system();          // every storing lane: rows before flags
+    __syncthreads();
+    if (threadIdx.x == 0 && a.prev_south) sys_store(a.prev_flag, a.seq);
+    if (threadIdx.x == 1 && a.next_north) sys_store(a.next_flag, a.seq);
+    if (threadIdx.x < 2) {
+        const unsigned long long* f = threadIdx.x == 0 ? a.my_north_flag : a.my_south_flag;
+        const bool owed = threadIdx.x == 0 ? a.prev_south != nullptr : a.next_north != nullptr;
+        unsigned spins = 0;
+        while (owed && sys_load(f) != a.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > XSPIN_LIMIT) { *a.timeout = 4; break; }
+        }
+    }
+    __threadfence_system();
 }
 
 // RCCL transport: fold this rank's block partials of slots [first, first+cnt) into the send buffer

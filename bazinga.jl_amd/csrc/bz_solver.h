@@ -121,6 +121,8 @@ struct SolverBase {
     virtual void eval_al_gradient(const void* x, void* dlx, double* vals3) = 0;
     virtual void eval_prox(const void* x, double gamma, void* z, double* gz) = 0;
     virtual void eval_lbfgs(int m, const void* S, const void* Y, const void* v, void* d) = 0;
+    virtual void halo_export(void* handle64) = 0;
+    virtual void halo_connect(const void* prev64, const void* next64) = 0;
     virtual void profile_enable(unsigned mask) = 0;
     virtual void profile_get(int cat, int64_t* launches, double* ms) = 0;
     virtual void profile_reset() = 0;

@@ -126,8 +126,10 @@ template <class T> class Solver final : public SolverBase {
                 throw Error(BZ_ERR_ARG, "Stencil5pt: grid nx*ny must equal n");
             if (d.f_grid_ny % PackN<T>::N != 0)
                 throw Error(BZ_ERR_ARG, "Stencil5pt: grid columns must be a multiple of 16 bytes");
-            if (ctx->nranks > 1)
-                throw Error(BZ_ERR_UNSUPPORTED, "Stencil5pt is not sharded (needs a halo exchange)");
+            // nranks > 1: the grid is sharded by row blocks in rank order (f_grid_nx = this rank's rows); the
+            // halo rows travel through IPC-mapped buffers (bz_problem_halo_export / _connect)
+            if (ctx->nranks > 1 && !ctx->p2p_on)
+                throw Error(BZ_ERR_UNSUPPORTED, "a sharded Stencil5pt needs the p2p mailboxes (bz_ctx_p2p_connect)");
         }
         if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_NORM_LP_BOX)
             throw Error(BZ_ERR_ARG, "unknown g kind");
@@ -254,6 +256,9 @@ template <class T> class Solver final : public SolverBase {
     ~Solver() override {
         for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto& e : ev_pool) (void)hipEventDestroy(e);
+        if (halo_prev_) (void)hipIpcCloseMemHandle(halo_prev_);
+        if (halo_next_) (void)hipIpcCloseMemHandle(halo_next_);
+        if (halo_local_) (void)hipFree(halo_local_);
         if (host_out_) (void)hipHostFree(host_out_);
         if (ptimeout_) (void)hipHostFree(ptimeout_);
     }
@@ -674,6 +679,69 @@ template <class T> class Solver final : public SolverBase {
         if (!active) throw Error(BZ_ERR_STATE, "no solve in progress (call bz_panoc_begin first)");
     }
 
+    // ---- row-block-sharded stencil: halo rows through IPC-mapped fine-grained buffers -------------------
+    // region layout: rows[parity][side][ny] of T (side 0 = north halo, written by the previous rank; side 1 =
+    // south halo, written by the next rank), then flags[parity][side] (64-byte aligned)
+    size_t halo_rows_bytes() const { return ((size_t)4 * desc.f_grid_ny * sizeof(T) + 63) / 64 * 64; }
+    size_t halo_bytes() const { return halo_rows_bytes() + 64; }
+    static T* halo_row(void* base, int par, int side, int64_t ny) { return (T*)base + (size_t)(par * 2 + side) * ny; }
+    unsigned long long* halo_flag(void* base, int par, int side) const {
+        return (unsigned long long*)((char*)base + halo_rows_bytes()) + (par * 2 + side);
+    }
+    bool sharded_stencil() const { return desc.f_kind == BZ_F_STENCIL5 && ctx->nranks > 1; }
+   public:
+    void halo_export(void* handle64) override {
+        if (!sharded_stencil()) throw Error(BZ_ERR_STATE, "halo buffers exist only for a sharded Stencil5pt problem");
+        BZ_HIP(hipSetDevice(ctx->device));
+        if (!halo_local_) {
+            BZ_HIP(hipExtMallocWithFlags(&halo_local_, halo_bytes(), hipDeviceMallocFinegrained));
+            BZ_HIP(hipMemset(halo_local_, 0, halo_bytes()));
+            BZ_HIP(hipDeviceSynchronize());
+        }
+        hipIpcMemHandle_t h;
+        BZ_HIP(hipIpcGetMemHandle(&h, halo_local_));
+        std::memcpy(handle64, &h, sizeof(h));
+    }
+    // handles of the previous and the next rank's halo regions (ignored at the two ends of the rank order)
+    void halo_connect(const void* prev64, const void* next64) override {
+        if (!halo_local_) throw Error(BZ_ERR_STATE, "bz_problem_halo_export must be called first");
+        BZ_HIP(hipSetDevice(ctx->device));
+        auto open = [&](const void* h64, void** out) {
+            if (!h64) throw Error(BZ_ERR_ARG, "missing neighbour halo handle");
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, h64, sizeof(h));
+            BZ_HIP(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+        };
+        if (ctx->rank > 0 && !halo_prev_) open(prev64, &halo_prev_);
+        if (ctx->rank + 1 < ctx->nranks && !halo_next_) open(next64, &halo_next_);
+        halo_connected_ = true;
+    }
+   private:
+    // exchange the boundary rows of v with the neighbours; the halo the stencil kernel then reads
+    StencilHalo<T> halo_exchange(const T* v) {
+        if (!sharded_stencil()) return StencilHalo<T>{nullptr, nullptr};
+        if (!halo_connected_) throw Error(BZ_ERR_STATE, "sharded Stencil5pt: bz_problem_halo_connect has not been called");
+        const int64_t gny = desc.f_grid_ny, rows = desc.f_grid_nx;
+        const unsigned long long seq = ++hseq_;
+        const int par = (int)(seq & 1ull);
+        HaloArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        a.first_row = v; a.last_row = v + (size_t)(rows - 1) * gny;
+        a.seq = seq; a.ny = gny; a.timeout = ptimeout_dev_;
+        if (halo_prev_) { a.prev_south = halo_row(halo_prev_, par, 1, gny); a.prev_flag = halo_flag(halo_prev_, par, 1); }
+        if (halo_next_) { a.next_north = halo_row(halo_next_, par, 0, gny); a.next_flag = halo_flag(halo_next_, par, 0); }
+        a.my_north_flag = halo_flag(halo_local_, par, 0);
+        a.my_south_flag = halo_flag(halo_local_, par, 1);
+        launch_b(C_GATHER, k_halo_exchange<T>, 1, XBLOCK, a);
+        return StencilHalo<T>{halo_prev_ ? halo_row(halo_local_, par, 0, gny) : nullptr,
+                              halo_next_ ? halo_row(halo_local_, par, 1, gny) : nullptr};
+    }
+    void* halo_local_ = nullptr;
+    void* halo_prev_ = nullptr;
+    void* halo_next_ = nullptr;
+    bool halo_connected_ = false;
+    unsigned long long hseq_ = 0;
+
     // multi-GPU: fold this rank's block partials of slots [first, first+cnt) and all-gather
     void gather(int first, int cnt, unsigned maxmask) {
         if (!ctx->multi()) return;
@@ -773,6 +841,7 @@ template <class T> class Solver final : public SolverBase {
             throw Error(code == 1 ? BZ_ERR_HIP : BZ_ERR_COMM,
                         code == 1 ? "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)"
                         : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
+                        : code == 4 ? "stencil halo exchange timed out waiting for a neighbour rank"
                                     : "persistent two-loop kernel: p2p phase exchange timed out waiting for a peer rank");
         }
         std::vector<double> out(a.n);
@@ -882,7 +951,7 @@ template <class T> class Solver final : public SolverBase {
                 launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 2, (const T*)FR_.p);
         } else if (desc.f_kind == BZ_F_STENCIL5) {
             launch(C_ALGRAD, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 0,
-                   grad, n, parts_.p, slot0);
+                   grad, n, parts_.p, slot0, halo_exchange(x));
         } else {
             launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 0, (const T*)nullptr);
         }
@@ -903,7 +972,7 @@ template <class T> class Solver final : public SolverBase {
                 launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0, (const T*)FR_.p);
         } else if (desc.f_kind == BZ_F_STENCIL5) {
             launch(C_MISC, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 1,
-                   (T*)nullptr, n, parts_.p, slot0);
+                   (T*)nullptr, n, parts_.p, slot0, halo_exchange(x));
         } else {
             launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0, (const T*)nullptr);
         }

@@ -128,6 +128,18 @@ class Problem:
         x0 = self._in(x0, self.n)
         L.check(L.load().bz_panoc_begin(self._h, C.byref(opts), x0.ctypes.data))
 
+    def halo_export(self) -> bytes:
+        """Row-block-sharded Stencil5ptQuadratic: this rank's halo region (64-byte IPC handle)."""
+        buf = C.create_string_buffer(64)
+        L.check(L.load().bz_problem_halo_export(self._h, buf))
+        return buf.raw
+
+    def halo_connect(self, prev: bytes | None, nxt: bytes | None):
+        """Handles of the previous / next rank's halo regions (None at the ends of the rank order)."""
+        a = C.create_string_buffer(prev, 64) if prev else None
+        b = C.create_string_buffer(nxt, 64) if nxt else None
+        L.check(L.load().bz_problem_halo_connect(self._h, a, b))
+
     def panoc_step(self):
         L.check(L.load().bz_panoc_step(self._h))
 

@@ -194,7 +194,7 @@ def als(f, g, c, D, x0, y0, **kw):
 def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol=None, maxit=100,
          theta_penalty=0.8, kappa_penalty=0.5, kappa_tol=0.1, verbose=False,
          dual_safeguard=default_dual_safeguard, subsolver=default_subsolver,
-         subsolver_maxit=1_000_000_000, resident=None, ctx=None, _slack=False):
+         subsolver_maxit=1_000_000_000, resident=None, ctx=None, problem=None, _slack=False):
     """Bazinga.alps (src/algorithms/alps.jl:7-117): same keywords and defaults, same 10-tuple
     ``(x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu)``
     (status is the Symbol's name as a string).  x0 / y0 are never mutated.
@@ -202,12 +202,17 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     resident=True (default when `subsolver` and `dual_safeguard` are the defaults) runs the
     whole outer loop with device-resident vectors (bz_alps_solve): only scalars cross PCIe
     between subproblems.  resident=False runs the outer loop below on the host exactly as
-    alps.jl does and enters the device at the `subsolver` seam."""
+    alps.jl does and enters the device at the `subsolver` seam.
+
+    problem: an already created device Problem for (f, g, c, D) to run the resident loop on — what a sharded
+    Stencil5ptQuadratic needs, whose halo regions must be connected between the ranks first."""
     x0 = np.asarray(x0)
     y0 = np.asarray(y0)
     T = x0.dtype.type
     if tol is None:
         tol = T(1e-6)
+    if problem is not None:
+        resident = True
     tol_prim = tol if tol_prim is None else tol_prim
     tol_dual = tol if tol_dual is None else tol_dual
     inner_tol = float(np.cbrt(tol_dual)) if inner_tol is None else inner_tol
@@ -218,14 +223,15 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         sub = subsolver(tol=inner_tol, verbose=verbose)
         if not isinstance(sub, PANOCplus):
             raise UnsupportedOracle("resident=True needs a PANOCplus subsolver factory")
-        prob = Problem(f, g, c, D, x0.shape[0], y0.shape[0], x0.dtype, ctx or sub.ctx, slack=_slack)
+        prob = problem or Problem(f, g, c, D, x0.shape[0], y0.shape[0], x0.dtype, ctx or sub.ctx, slack=_slack)
         ao = L.AlpsOpts()
         L.load().bz_alps_default_opts(C.byref(ao), L.BZ_F64 if x0.dtype == np.float64 else L.BZ_F32)
         ao.tol_prim, ao.tol_dual, ao.inner_tol = float(tol_prim), float(tol_dual), float(inner_tol)
         ao.maxit, ao.theta_penalty, ao.kappa_penalty = int(maxit), float(theta_penalty), float(kappa_penalty)
         ao.kappa_tol, ao.subsolver_maxit, ao.verbose = float(kappa_tol), int(subsolver_maxit), int(bool(verbose))
         x, y, s, mu, st = prob.alps_solve(ao, sub.c_opts(), x0, y0)
-        prob.close()
+        if problem is None:
+            prob.close()
         return (x, y, int(st.tot_it), int(st.tot_inner_it), st.elapsed_s, _STATUS[st.status],
                 st.inner_tol, st.norm_res_prim if st.tot_it else None, s, mu)
 

@@ -141,6 +141,16 @@ typedef struct {
 int  bz_problem_create(bz_ctx* ctx, const bz_problem_desc* desc, bz_problem** out);
 void bz_problem_destroy(bz_problem* p);
 
+/* BZ_F_STENCIL5 with x sharded over the ranks of a node (cfg 3): the grid is cut into
+ * row blocks in rank order — desc.f_grid_nx is THIS rank's number of rows, desc.n = f_grid_nx * f_grid_ny —
+ * and before every stencil evaluation the boundary rows are exchanged with the two neighbour ranks
+ * straight through IPC-mapped device buffers (no collective).  After bz_problem_create on a context whose
+ * mailboxes are connected (bz_ctx_p2p_connect): export this problem's halo region, hand the 64-byte
+ * handles to the neighbours (any host channel), connect.  prev64 / next64 are ignored on the first / last
+ * rank (pass NULL there).                                                                              */
+int bz_problem_halo_export(bz_problem* p, void* handle64);
+int bz_problem_halo_connect(bz_problem* p, const void* prev64, const void* next64);
+
 /* ---- inner solver: replaces  ProximalAlgorithms.PANOCplus(...)(f=alFun,g=gFun,x0=x)
  *      at src/algorithms/alps.jl:64-66 ------------------------------------------- */
 typedef struct {

@@ -222,9 +222,11 @@ def side_workload(args):
                           bz.ClosedSet(bz.IndBox(d["psi"], np.inf)), n, ny, dt)
         x0, mg = d["x0"], eps64
         b_iter = 63 * w * n            # 63 passes
-        cat_name, label = "k_axpy_dot", "cfg3: 5-pt stencil QP on 2048^2 grid fp64, box D, g=Zero, LBFGS(5)"
-        launch_bytes = lambda m: ((4.0 * (2 * m - 2) + 3.0) / (2 * m - 1)) * w * n
-        kernel = "bz::k_axpy_dot<double>"
+        # the register-resident two-loop kernel is the largest single launch here: model (8m+1) - 4 passes
+        # (the last axpy is k_axpy_dot's), it moves 4m
+        cat_name, label = "k_twoloop_persist", "cfg3: 5-pt stencil QP on 2048^2 grid fp64, box D, g=Zero, LBFGS(5)"
+        launch_bytes = lambda m: ((8 * m + 1) - 4) * w * n
+        kernel = "bz::k_twoloop_persist<double>"
     else:
         ny, n = 8192, 65536
         d = bz.synth.basis_pursuit(ny, n, dtype=np.float32)

@@ -957,7 +957,16 @@ struct XchgArgs {
 // exchange's sequence number, so a word is valid exactly when its tag matches — no separate flag, no
 // fence between data and flag, one store latency + one load latency per exchange.  8-byte stores are
 // single-copy atomic, and each half is checked against its own tag, so a torn pair cannot be taken.
-__device__ __forceinline__ unsigned ll_tag(unsigned long long seq) { return (unsigned)(seq & 0x7FFFFFFFull) + 1u; }
+__device__ __host__ __forceinline__ unsigned ll_tag(unsigned long long seq) { return (unsigned)(seq & 0x7FFFFFFFull) + 1u; }
+// the same tagged form towards the host's pinned mailbox: two 8-byte words per scalar, no fence; the host
+// takes a scalar when both of its words carry the tag of the read-back it is waiting for
+__device__ __forceinline__ void host_post(double* out, int i, double v, unsigned long long seq) {
+    const unsigned long long tag = (unsigned long long)ll_tag(seq) << 32;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    unsigned long long* dst = (unsigned long long*)out + 2 * i;
+    sys_store(dst + 0, tag | (bits & 0xFFFFFFFFull));
+    sys_store(dst + 1, tag | (bits >> 32));
+}
 static __global__ void __launch_bounds__(XBLOCK) k_exchange(XchgArgs a) {
     __shared__ double vals[32];
     const int tid = threadIdx.x;
@@ -993,7 +1002,7 @@ static __global__ void __launch_bounds__(XBLOCK) k_exchange(XchgArgs a) {
 struct XCollectArgs {
     XchgArgs x;
     double* host_out;
-    double ticket;
+    unsigned long long ticket;
 };
 static __global__ void __launch_bounds__(XBLOCK) k_exchange_collect(XCollectArgs b) {
     const XchgArgs& a = b.x;
@@ -1032,9 +1041,7 @@ static __global__ void __launch_bounds__(XBLOCK) k_exchange_collect(XCollectArgs
         const bool ismax = (a.maxmask >> tid) & 1u;
         double g = 0.0;
         for (int r = 0; r < a.nranks; ++r) g = ismax ? nanmax(g, got[r][tid]) : g + got[r][tid];
-        __hip_atomic_store(b.host_out + 2 * tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __threadfence_system();                       // value before ticket
-        __hip_atomic_store(b.host_out + 2 * tid + 1, b.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        host_post(b.host_out, tid, g, b.ticket);
     }
 }
 
@@ -2123,10 +2130,11 @@ struct CollectArgs {
     ScalarSrc src[MAX_COLLECT];
     unsigned maxmask;
     int n;
-    double ticket;      // sequence number of this read-back
+    unsigned long long ticket;      // sequence number of this read-back
 };
-// one block per source: fold it and write {scalar, ticket} to the (host-mapped) mailbox `out`; the host
-// spins on the tickets instead of paying a blocking stream synchronisation
+// one block per source: fold it and post it (tagged words, host_post) to the host-mapped mailbox `out`; the
+// host spins on the tags instead of paying a blocking stream synchronisation.  (One 1024-thread block folding
+// all 32 sources, 16 at a time, measured slower: 8.6 us against 5.5 us for 32 small blocks.)
 __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out);
 
 }  // namespace bz

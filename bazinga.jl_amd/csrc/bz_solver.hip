@@ -79,11 +79,7 @@ __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out) {
     __shared__ double sh[WAVES];
     const int i = blockIdx.x;
     double t = fold_src(a.src[i], (a.maxmask >> i) & 1u, sh);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(out + 2 * i, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __threadfence_system();                       // value before ticket
-        __hip_atomic_store(out + 2 * i + 1, a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) host_post(out, i, t, a.ticket);
 }
 
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
@@ -770,7 +766,7 @@ template <class T> class Solver final : public SolverBase {
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
     }
     // p2p transport: k_exchange and the read-back in one launch; returns the ticket wait_host must see
-    double exchange_collect(int first, int cnt, unsigned maxmask) {
+    unsigned long long exchange_collect(int first, int cnt, unsigned maxmask) {
         if (cnt > P2P_PACK) throw Error(BZ_ERR_ARG, "pack too large for the p2p mailbox");
         XCollectArgs b;
         std::memset(&b, 0, sizeof(b));
@@ -783,7 +779,7 @@ template <class T> class Solver final : public SolverBase {
         for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
         a.timeout = ptimeout_dev_;
         b.host_out = host_out_dev_;
-        b.ticket = (double)(++collect_seq);
+        b.ticket = ++collect_seq;
         launch_b(C_GATHER, k_exchange_collect, 1, XBLOCK, b);
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
         return b.ticket;
@@ -810,23 +806,25 @@ template <class T> class Solver final : public SolverBase {
         return collect_run(a);
     }
     std::vector<double> collect_run(CollectArgs& a) {
-        a.ticket = (double)(++collect_seq);
+        a.ticket = ++collect_seq;
         launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
         return wait_host(a.n, a.ticket);
     }
-    // read n {value, ticket} pairs from the pinned mailbox once all carry `ticket`
-    std::vector<double> wait_host(int cnt, double ticket) {
-        struct { int n; double ticket; } a{cnt, ticket};
+    // read n scalars from the pinned mailbox once both tagged words of each carry this read-back's tag
+    std::vector<double> wait_host(int cnt, unsigned long long ticket) {
+        struct { int n; } a{cnt};
+        const unsigned long long tag = (unsigned long long)ll_tag(ticket) << 32;
+        const unsigned long long himask = 0xFFFFFFFF00000000ull;
         // spin on the tickets in pinned host memory (a few microseconds after the kernel's stores land);
         // bounded: on a fault or a hang fall through to the blocking synchronisation, which reports it
         {
-            volatile double* ho = host_out_;
+            volatile unsigned long long* ho = (volatile unsigned long long*)host_out_;
             const auto t_start = std::chrono::steady_clock::now();
             bool done = false;
             for (unsigned spin = 0; !done; ++spin) {
                 done = true;
                 for (int i = 0; i < a.n; ++i)
-                    if (ho[2 * i + 1] != a.ticket) { done = false; break; }
+                    if ((ho[2 * i] & himask) != tag || (ho[2 * i + 1] & himask) != tag) { done = false; break; }
                 if (!done && (spin & 0x3FFu) == 0x3FFu) {
                     if (hipStreamQuery(ctx->stream) != hipErrorNotReady) break;     // finished or failed
                     if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) break;
@@ -845,7 +843,11 @@ template <class T> class Solver final : public SolverBase {
                                     : "persistent two-loop kernel: p2p phase exchange timed out waiting for a peer rank");
         }
         std::vector<double> out(a.n);
-        for (int i = 0; i < a.n; ++i) out[i] = host_out_[2 * i];
+        const unsigned long long* hw = (const unsigned long long*)host_out_;
+        for (int i = 0; i < a.n; ++i) {
+            const unsigned long long bits = (hw[2 * i] & 0xFFFFFFFFull) | (hw[2 * i + 1] << 32);
+            std::memcpy(&out[i], &bits, sizeof(double));
+        }
         return out;
     }
 
@@ -1333,7 +1335,7 @@ template <class T> class Solver final : public SolverBase {
         static_assert(SL_TRIAL + NFC <= SL_AUX, "k_fused_compact's slots overlap the next group");
         const int m_at_trial = (int)order.size();
         bool tail_used = false;
-        double tail_ticket = 0.0;
+        unsigned long long tail_ticket = 0;
         bool gram_from_trial = false;
         tau = T(1);
         const int xp = xc, xd = (xc + 1) % 3, xb = (xc + 2) % 3;

@@ -22,8 +22,9 @@ def cfg2_problem(n):
                R.ClosedSet(R.IndBox(d["lo"], d["hi"])))
 
 
-def cfg2_trace(n, iters):
-    """First `iters` PANOCplus states on the cfg-2 problem with mu = 0.1, y = sin(i)."""
+def cfg2_trace(n, iters, compact=False):
+    """First `iters` PANOCplus states on the cfg-2 problem with mu = 0.1, y = sin(i); compact: the L-BFGS
+    operator in its compact representation (LBFGSCompactOperator)."""
     from oracle import bazinga_ref as R
     d, (f, g, c, D) = cfg2_problem(n)
     mu = np.full(n, 0.1)
@@ -31,7 +32,7 @@ def cfg2_trace(n, iters):
     x0 = np.zeros(n)
     al = R.AugLagFun(f, c, D, mu, y, x0)
     gF = R.NonsmoothCostFun(g)
-    it = R.PANOCplusIteration(al, gF, x0, minimum_gamma=np.finfo(float).eps)
+    it = R.PANOCplusIteration(al, gF, x0, minimum_gamma=np.finfo(float).eps, directions=R.LBFGS(5, compact=compact))
     st = it.init()
     rows = []
     for k in range(1, iters + 1):
@@ -40,7 +41,23 @@ def cfg2_trace(n, iters):
                      "x": st.x.tolist(), "z": st.z.tolist()})
         if k < iters:
             st = it.step(st)
-    return {"n": n, "iters": iters, "mu": 0.1, "y": "sin(i)", "rows": rows}
+    return {"n": n, "iters": iters, "mu": 0.1, "y": "sin(i)", "compact": compact, "rows": rows}
+
+
+def pairs_problem(n, kind):
+    import bazinga_jl_amd as bz
+    from oracle import bazinga_ref as R
+    d = bz.synth.l1_quadratic(n)
+    return d, (R.DiagQuadratic(d["q"], 0.2 * d["b"]), R.NormL1(0.3), R.IdentityFunction(), R.PairwiseSet(kind))
+
+
+def pairs_alps(n, kind):
+    """ALPS with D = the 2-element set `kind` over adjacent pairs (nonconvex)."""
+    from oracle import bazinga_ref as R
+    d, orc = pairs_problem(n, kind)
+    out = R.alps(*orc, np.zeros(n), np.zeros(n))
+    return {"n": n, "kind": kind, "x": out[0].tolist(), "y": out[1].tolist(), "tot_it": out[2],
+            "tot_inner_it": out[3], "status": out[5]}
 
 
 def cfg2_alps(n):
@@ -57,6 +74,10 @@ def main():
         json.dump(cfg2_trace(64, 25), fh)
     with open(os.path.join(here, "alps_cfg2_n256.json"), "w") as fh:
         json.dump(cfg2_alps(256), fh)
+    with open(os.path.join(here, "panoc_trace_cfg2_n64_compact.json"), "w") as fh:
+        json.dump(cfg2_trace(64, 25, compact=True), fh)
+    with open(os.path.join(here, "alps_pairs_n128.json"), "w") as fh:
+        json.dump({k: pairs_alps(128, k) for k in ("vc", "cc", "eitheror", "xor")}, fh)
     print("golden fixtures written")
 
 

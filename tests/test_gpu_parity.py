@@ -885,3 +885,46 @@ def test_compact_lbfgs_float32_and_short_memory(bz, ref, M):
     o = ref.alps(*orc64, x0, y0, subsolver=lambda **kw: ref.PANOCplus(directions=ref.LBFGS(M, compact=True), **kw))
     assert a[5] == o[5] == "first_order" and a[2] == o[2] and abs(a[3] - o[3]) <= max(3, 0.05 * o[3])
     assert rel(a[0], o[0]) <= 1e-8
+
+
+# ------------------------------------------------------------------ the device against the committed fixtures
+def test_device_matches_golden_fixtures(bz, ref):
+    """tests/golden/*.json (restatement-generated, committed with the script that made them): the HIP path
+    reproduces the recorded PANOCplus states — both evaluations of the L-BFGS operator — and the recorded
+    ALPS solves (cfg 2 and the four pairwise sets) without the oracle in the loop."""
+    import json
+    import os
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, compact in (("panoc_trace_cfg2_n64.json", False), ("panoc_trace_cfg2_n64_compact.json", True)):
+        with open(os.path.join(gold_dir, name)) as fh:
+            gold = json.load(fh)
+        n = gold["n"]
+        d, dev, _ = make_cfg2(bz, ref, n)
+        prob = bz.Problem(*dev, n, n, np.float64)
+        prob.set_multipliers(np.full(n, 0.1), np.sin(np.arange(n, dtype=np.float64)))
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps),
+                                      directions=bz.LBFGS(5, compact=compact)).c_opts(), np.zeros(n))
+        for row in gold["rows"]:
+            sc = prob.panoc_scalars()
+            assert int(sc["k"]) == row["k"]
+            assert abs(sc["gamma"] - row["gamma"]) <= 1e-13 * row["gamma"]
+            assert rel(prob.panoc_vector("x"), np.array(row["x"])) <= RTOL_ITER, (name, row["k"])
+            assert rel(prob.panoc_vector("z"), np.array(row["z"])) <= RTOL_ITER, (name, row["k"])
+            assert abs(sc["stop_norm"] - row["stop_norm"]) <= 1e-9 * max(1.0, row["stop_norm"])
+            prob.panoc_step()
+        prob.close()
+    with open(os.path.join(gold_dir, "alps_cfg2_n256.json")) as fh:
+        gold = json.load(fh)
+    n = gold["n"]
+    d, dev, _ = make_cfg2(bz, ref, n)
+    a = bz.alps(*dev, np.zeros(n), np.zeros(n))
+    assert a[5] == gold["status"] and a[2] == gold["tot_it"] and a[3] == gold["tot_inner_it"]
+    assert rel(a[0], np.array(gold["x"])) <= 1e-9 and rel(a[9], np.array(gold["mu"])) <= 1e-12
+    with open(os.path.join(gold_dir, "alps_pairs_n128.json")) as fh:
+        goldp = json.load(fh)
+    for kind, g in goldp.items():
+        n = g["n"]
+        dev, _ = make_pairs(bz, ref, n, kind, "l1")
+        a = bz.alps(*dev, np.zeros(n), np.zeros(n))
+        assert a[5] == g["status"] and a[2] == g["tot_it"] and abs(a[3] - g["tot_inner_it"]) <= 2, kind
+        assert rel(a[0], np.array(g["x"])) <= 1e-8, kind

@@ -148,6 +148,20 @@ def test_golden_traces():
         assert a["gamma"] == b["gamma"]
         assert np.allclose(a["x"], b["x"], rtol=1e-12, atol=1e-14)
         assert np.allclose(a["z"], b["z"], rtol=1e-12, atol=1e-14)
+    with open(os.path.join(GOLD, "panoc_trace_cfg2_n64_compact.json")) as fh:
+        goldc = json.load(fh)
+    nowc = cfg2_trace(goldc["n"], goldc["iters"], compact=True)
+    for a, b, t in zip(nowc["rows"], goldc["rows"], gold["rows"]):
+        assert a["gamma"] == b["gamma"]
+        assert np.allclose(a["x"], b["x"], rtol=1e-12, atol=1e-14)
+        assert np.allclose(a["z"], t["z"], rtol=1e-9, atol=1e-12)       # the two forms are the same operator
+    from tests.golden.make_golden import pairs_alps
+    with open(os.path.join(GOLD, "alps_pairs_n128.json")) as fh:
+        goldp = json.load(fh)
+    for kind, g in goldp.items():
+        nowp = pairs_alps(g["n"], kind)
+        assert nowp["status"] == g["status"] and nowp["tot_it"] == g["tot_it"] and nowp["tot_inner_it"] == g["tot_inner_it"]
+        assert np.allclose(nowp["x"], g["x"], rtol=1e-12, atol=1e-14)
 
 
 def test_als_rosenbrock_and_agrees_with_alps():

@@ -1,4 +1,5 @@
 // bz_capi.hip — the extern "C" surface declared in include/bazinga_hip.h.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -16,6 +17,20 @@ struct bz_problem {
 
 namespace {
 thread_local std::string g_err;
+
+// ROCm runtime settings for a launch-latency-bound host loop (one short kernel chain per PANOC iteration,
+// the host in the loop between them), applied when the library is loaded, i.e. before the HIP runtime
+// initialises — unless the process has set them itself or BZ_NO_RUNTIME_TUNING is set:
+//   HIP_FORCE_DEV_KERNARG=1  kernel arguments live in device memory: the command processor does not fetch
+//                            them over PCIe at every launch
+//   HSA_ENABLE_INTERRUPT=0   completion signals are polled instead of interrupt-driven
+// measured together, same box, alternating runs at n = 1.25e6: 53.7 -> 52.0 us per iteration on average and a
+// narrower spread (52.2-56.3 -> 51.3-52.4); box-to-box differences are larger than that
+__attribute__((constructor)) void bz_runtime_tuning() {
+    if (std::getenv("BZ_NO_RUNTIME_TUNING")) return;
+    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+    setenv("HSA_ENABLE_INTERRUPT", "0", 0);
+}
 
 template <class F> int guard(F&& f) {
     try {

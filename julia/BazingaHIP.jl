@@ -44,6 +44,16 @@ Base.@kwdef mutable struct PanocStats
     n_lbfgs_skips::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; reserved::Int32 = 0
 end
 
+Base.@kwdef mutable struct AlpsOpts
+    tol_prim::Float64 = 1e-6; tol_dual::Float64 = 1e-6; inner_tol::Float64 = cbrt(1e-6)
+    maxit::Int64 = 100; theta_penalty::Float64 = 0.8; kappa_penalty::Float64 = 0.5; kappa_tol::Float64 = 0.1
+    subsolver_maxit::Int64 = 1_000_000_000; verbose::Int32 = 0; reserved::Int32 = 0
+end
+Base.@kwdef mutable struct AlpsStats
+    tot_it::Int64 = 0; tot_inner_it::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; reserved::Int32 = 0
+    inner_tol::Float64 = 0; norm_res_prim::Float64 = 0; objective::Float64 = 0
+end
+
 function check(rc::Cint)
     rc == 0 && return
     msg = unsafe_string(ccall((:bz_last_error, lib), Cstring, ()))
@@ -64,6 +74,24 @@ struct DiagQuadratic{T} <: Bazinga.ProximableFunction
     q::Vector{T}; b::Vector{T}            # f(x) = sum x_i (0.5 q_i x_i - b_i)
 end
 
+"f(x) = 0.5 x'A_h x - b'x, A_h the 5-point Laplacian (4,-1,-1,-1,-1) on an nx-by-ny grid, row-major, Dirichlet-0"
+struct Stencil5ptQuadratic{T} <: Bazinga.ProximableFunction
+    nx::Int; ny::Int; b::Vector{T}
+end
+"c(x) = A x - b with a dense A (demo/basispursuit.jl:38-49); `At` keeps A row-major for the device"
+struct DenseAffine{T} <: Bazinga.SmoothFunction
+    A::Matrix{T}; b::Vector{T}; At::Matrix{T}
+    DenseAffine(A::Matrix{T}, b::Vector{T}) where {T} = new{T}(A, b, permutedims(A))
+end
+Bazinga.eval!(cx, c::DenseAffine, x) = (cx .= c.A * x .- c.b; nothing)
+Bazinga.jtprod!(jtv, c::DenseAffine, x, v) = (jtv .= c.A' * v; nothing)
+
+"`LBFGS(M; compact = false)`: compact = true evaluates the same operator in its compact representation (bz_panoc_opts.lbfgs_compact)"
+struct LBFGS
+    memory::Int; compact::Bool
+    LBFGS(memory = 5; compact = false) = new(memory, compact)
+end
+
 # ---- lowering: pattern-match the oracle structs -> bz_problem_desc ----------------------------
 dtype_code(::Type{Float64}) = Int32(0)
 dtype_code(::Type{Float32}) = Int32(1)
@@ -71,6 +99,7 @@ dtype_code(::Type{Float32}) = Int32(1)
 lower_f!(d, f::Bazinga.Zero) = (d.f_kind = 0)
 lower_f!(d, f::ProximalOperators.Zero) = (d.f_kind = 0)
 lower_f!(d, f::DiagQuadratic) = (d.f_kind = 1; d.f_q = pointer(f.q); d.f_b = pointer(f.b))
+lower_f!(d, f::Stencil5ptQuadratic) = (d.f_kind = 2; d.f_grid_nx = f.nx; d.f_grid_ny = f.ny; d.f_b = pointer(f.b))
 # dense f: Julia matrices are column-major, the library wants row-major -> pass the transpose's memory
 lower_f!(d, f::ProximalOperators.LeastSquares) = (At = permutedims(f.A); d.f_kind = 3; d.f_A = pointer(At);
                                                   d.f_rows = size(f.A, 1); d.f_b = pointer(f.b); At)
@@ -93,6 +122,7 @@ lower_g!(d, g) = error("BazingaHIP: g of type $(typeof(g)) is not lowered to the
 # c: any SmoothFunction whose eval!/jtprod! are the identity (e.g. test/definitions/identityFunction.jl)
 abstract type IdentityLike <: Bazinga.SmoothFunction end
 lower_c!(d, c::IdentityLike) = (d.c_kind = 0)
+lower_c!(d, c::DenseAffine) = (d.c_kind = 1; d.c_A = pointer(c.At); d.c_b = pointer(c.b))
 lower_c!(d, c) = error("BazingaHIP: c of type $(typeof(c)) is not lowered to the device")
 
 lower_D!(d, D::Bazinga.ZeroSet) = (d.D_kind = 0)
@@ -142,9 +172,10 @@ as ProximalAlgorithms.PANOCplus as the reference configures it (demo/rosenbrock.
 function PANOCplus(; directions = nothing, maxit = 1000, tol = 1e-8, verbose = false, freq = 10,
                    minimum_gamma = 1e-7, alpha = 0.95, beta = 0.5, max_backtracks = 20, kwargs...)
     M = directions === nothing ? 5 : directions.memory
+    compact = directions isa LBFGS && directions.compact
     PANOCplusHIP(PanocOpts(tol = tol, maxit = min(maxit, typemax(Int64)), freq = min(freq, typemax(Int32)),
                            verbose = verbose, minimum_gamma = minimum_gamma, alpha = alpha, beta = beta,
-                           max_backtracks = max_backtracks, lbfgs_memory = M))
+                           max_backtracks = max_backtracks, lbfgs_memory = M, lbfgs_compact = compact))
 end
 
 const _problems = IdDict{Any,Problem}()
@@ -161,6 +192,29 @@ function (s::PANOCplusHIP)(; f::Bazinga.AugLagFun, g::Bazinga.NonsmoothCostFun, 
     g.gz = T(st[].g_z)
     g.gamma = st[].gamma
     return x, Int(st[].iters)
+end
+
+# ---- the whole outer loop with device-resident vectors (bz_alps_solve) --------------------------
+const _status = (:first_order, :max_iter, :exception, :unknown)          # alps.jl:105-113
+
+"""`alps(f, g, c, D, x0, y0; kw...)`: same keywords, defaults and 10-tuple as `Bazinga.alps` (alps.jl:14-25,115);
+only scalars cross PCIe between subproblems."""
+function alps(f, g, c, D, x0::AbstractVector{T}, y0::AbstractVector{T}; tol::Real = T(1e-6), tol_prim::Real = tol,
+              tol_dual::Real = tol, inner_tol::Real = cbrt(tol_dual), maxit::Integer = 100,
+              theta_penalty::Real = 0.8, kappa_penalty::Real = 0.5, kappa_tol::Real = 0.1, verbose::Bool = false,
+              subsolver = PANOCplus, subsolver_maxit::Integer = 1_000_000_000) where {T}
+    p = Problem(f, g, c, D, length(x0), length(y0), T)
+    ao = AlpsOpts(tol_prim = tol_prim, tol_dual = tol_dual, inner_tol = inner_tol, maxit = maxit,
+                  theta_penalty = theta_penalty, kappa_penalty = kappa_penalty, kappa_tol = kappa_tol,
+                  subsolver_maxit = subsolver_maxit, verbose = verbose)
+    po = subsolver(tol = inner_tol, verbose = verbose).opts
+    x = similar(x0); y = similar(y0); s = similar(y0); mu = similar(y0); st = Ref(AlpsStats())
+    check(ccall((:bz_alps_solve, lib), Cint,
+                (Ptr{Cvoid}, Ref{AlpsOpts}, Ref{PanocOpts}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{AlpsStats}),
+                p.h, Ref(ao), Ref(po), x0, y0, x, y, s, mu, st))
+    r = st[]
+    return x, y, Int(r.tot_it), Int(r.tot_inner_it), r.elapsed_s, _status[r.status + 1], T(r.inner_tol),
+           T(r.norm_res_prim), s, mu
 end
 
 end # module

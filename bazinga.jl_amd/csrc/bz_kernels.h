@@ -205,6 +205,28 @@ __device__ __forceinline__ void stp(T* __restrict__ p, int64_t i0, int cnt, cons
             if (e < cnt) p[i0 + e] = r.v[e];
     }
 }
+// full packs addressed as (uniform base pointer, 32-bit byte offset): the offset is ONE vector register
+// shared by every stream of a kernel, the bases stay in scalar registers (saddr addressing)
+template <class T, bool NT>
+__device__ __forceinline__ Pack<T> ldo(const T* __restrict__ base, unsigned byte_off) {
+    using V = typename PackVec<T>::type;
+    const V* p = reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off);
+    V v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p); else v = *p;
+    Pack<T> r;
+#pragma unroll
+    for (int e = 0; e < PackN<T>::N; ++e) r.v[e] = v[e];
+    return r;
+}
+template <class T, bool NT>
+__device__ __forceinline__ void sto(T* __restrict__ base, unsigned byte_off, const Pack<T>& r) {
+    using V = typename PackVec<T>::type;
+    V v;
+#pragma unroll
+    for (int e = 0; e < PackN<T>::N; ++e) v[e] = r.v[e];
+    V* p = reinterpret_cast<V*>(reinterpret_cast<char*>(base) + byte_off);
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
 template <class T> __device__ __forceinline__ Pack<T> splat(T s) {
     Pack<T> r;
 #pragma unroll
@@ -1819,7 +1841,7 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
 //           + 10 + 2MM + i: <s_i, -res> ; + 10 + 3MM + i: <y_i, -res> ; then <s_new, -res>, <y_new, -res>
 //           with res the NEW residual: the p and w of the next application, whichever pairs it keeps —
 //           so the whole iteration is this one pass (S and Y are in registers here anyway)
-template <class T, int MM, bool NT, bool SPEC>
+template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
@@ -1836,7 +1858,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     compact_coefs<T, MM>(C, u1, u2h);
     T H0 = (T)C.H0;
     T gl = gamma * P.g_lambda;
-    if (SPEC) {      // keep the per-application coefficients in vector registers: scalar ones are the scarce kind here
+    if (SPEC && !OFF32) {      // keep the per-application coefficients in vector registers: scalar ones are the scarce kind here
 #pragma unroll
         for (int i = 0; i < MM; ++i) { asm volatile("" : "+v"(u1[i])); asm volatile("" : "+v"(u2h[i])); }
         asm volatile("" : "+v"(H0));
@@ -1849,19 +1871,34 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
+        // full chunks of a vector shorter than 4 GiB: every stream is (scalar base, one shared 32-bit offset)
+        constexpr bool O32 = SPEC && OFF32 && !std::is_integral<std::remove_cv_t<decltype(cnt_)>>::value;
+        unsigned bo = (unsigned)(i0 * (int64_t)sizeof(T));
+        if constexpr (O32) asm volatile("" : "+v"(bo));      // opaque: no per-stream 64-bit pointer induction variables
         ElemLoads<T> L;
-        if (SPEC) {
-            L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
-            L.mu = ldp<T, NT>(P.mu, i0, cnt); L.muy = ldp<T, NT>(P.muy, i0, cnt);
+        Pack<T> px, prp, ps[MM], py[MM], d;
+        if constexpr (O32) {
+            L.q = ldo<T, NT>(P.q, bo); L.b = ldo<T, NT>(P.b, bo);
+            L.mu = ldo<T, NT>(P.mu, bo); L.muy = ldo<T, NT>(P.muy, bo);
             L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
             L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
-        } else {
-            load_params<T, NT>(P, i0, cnt, L, true, true, true);
-        }
-        Pack<T> px = ldp<T, NT>(x, i0, cnt), prp = ldp<T, NT>(res_prev, i0, cnt), ps[MM], py[MM], d;
+            px = ldo<T, NT>(x, bo); prp = ldo<T, NT>(res_prev, bo);
 #pragma unroll
-        for (int i = 0; i < MM; ++i)
-            if (i < m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
+            for (int i = 0; i < MM; ++i) { ps[i] = ldo<T, NT>(V.S[i], bo); py[i] = ldo<T, NT>(V.Y[i], bo); }
+        } else {
+            if (SPEC) {
+                L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
+                L.mu = ldp<T, NT>(P.mu, i0, cnt); L.muy = ldp<T, NT>(P.muy, i0, cnt);
+                L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
+                L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
+            } else {
+                load_params<T, NT>(P, i0, cnt, L, true, true, true);
+            }
+            px = ldp<T, NT>(x, i0, cnt); prp = ldp<T, NT>(res_prev, i0, cnt);
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
+        }
         compact_d<T, MM>(m, H0, u1, u2h, prp, ps, py, d);
         Pack<T> pxd, pz, pr, pss, pyy;
 #pragma unroll
@@ -1910,11 +1947,16 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                 acc[10 + 4 * MM + 1] += (double)(yy * nr);
             }
         }
-        stp<T, NT>(x_d, i0, cnt, pxd);
-        stp<T, NT>(z, i0, cnt, pz);
-        stp<T, NT>(res, i0, cnt, pr);
-        stp<T, NT>(s_new, i0, cnt, pss);
-        stp<T, NT>(y_new, i0, cnt, pyy);
+        if constexpr (O32) {
+            sto<T, NT>(x_d, bo, pxd); sto<T, NT>(z, bo, pz); sto<T, NT>(res, bo, pr);
+            sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy);
+        } else {
+            stp<T, NT>(x_d, i0, cnt, pxd);
+            stp<T, NT>(z, i0, cnt, pz);
+            stp<T, NT>(res, i0, cnt, pr);
+            stp<T, NT>(s_new, i0, cnt, pss);
+            stp<T, NT>(y_new, i0, cnt, pyy);
+        }
     });
     block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
 }

@@ -1359,10 +1359,18 @@ template <class T> class Solver final : public SolverBase {
 #define BZ_LAUNCH_FC(NT_, SPEC_)                                                                                  \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, SPEC_>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
-            if (nt && spec) BZ_LAUNCH_FC(true, true);
+            static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
+            const bool off32 = off32_env && spec && (double)vcap * sizeof(T) < 4.0e9;
+#define BZ_LAUNCH_FC3(NT_)                                                                                        \
+    launch(C_FUSED, k_fused_compact<T, CM, NT_, true, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
+           gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
+            if (off32 && nt) BZ_LAUNCH_FC3(true);
+            else if (off32) BZ_LAUNCH_FC3(false);
+            else if (nt && spec) BZ_LAUNCH_FC(true, true);
             else if (nt) BZ_LAUNCH_FC(true, false);
             else if (spec) BZ_LAUNCH_FC(false, true);
             else BZ_LAUNCH_FC(false, false);
+#undef BZ_LAUNCH_FC3
 #undef BZ_LAUNCH_FC
             if (ctx->p2p_on) {
                 // exchange + fold over the ranks + read-back in one launch (no k_collect)

@@ -95,6 +95,8 @@ SIGNATURES = {
     "bz_panoc_begin": (C.c_int, [_vp, _P(PanocOpts), _vp]),
     "bz_problem_halo_export": (C.c_int, [_vp, _vp]),
     "bz_problem_halo_connect": (C.c_int, [_vp, _vp, _vp]),
+    "bz_problem_allreduce_export": (C.c_int, [_vp, _vp]),
+    "bz_problem_allreduce_connect": (C.c_int, [_vp, _vp]),
     "bz_panoc_step": (C.c_int, [_vp]),
     "bz_panoc_steps": (C.c_int, [_vp, C.c_int64]),
     "bz_panoc_finish": (C.c_int, [_vp, _vp, _P(PanocStats)]),

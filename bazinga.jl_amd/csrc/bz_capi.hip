@@ -240,6 +240,13 @@ int bz_problem_halo_connect(bz_problem* p, const void* prev64, const void* next6
     return guard([&] { need(p, "problem"); p->s->halo_connect(prev64, next64); });
 }
 
+int bz_problem_allreduce_export(bz_problem* p, void* handle64) {
+    return guard([&] { need(p, "problem"); need(handle64, "handle64"); p->s->allreduce_export(handle64); });
+}
+int bz_problem_allreduce_connect(bz_problem* p, const void* handles) {
+    return guard([&] { need(p, "problem"); need(handles, "handles"); p->s->allreduce_connect(handles); });
+}
+
 int bz_profile_enable(bz_problem* p, int32_t on) {
     return guard([&] { need(p, "problem"); p->s->profile_enable((unsigned)on); });
 }

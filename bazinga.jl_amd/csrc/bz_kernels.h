@@ -974,6 +974,8 @@ struct XchgArgs {
     P2PWords* mbox_local;
     P2PWords* mbox_peer[8];
     int* timeout;
+    unsigned keepmask;       // bit i clear: slot first+i holds a quantity every rank computed in full (x is
+                             // replicated, e.g. with a row-sharded dense c): only rank 0's copy is counted
 };
 // The pack travels in "LL" form: every 8-byte word carries half a value and a 32-bit tag of the
 // exchange's sequence number, so a word is valid exactly when its tag matches — no separate flag, no
@@ -993,7 +995,8 @@ static __global__ void __launch_bounds__(XBLOCK) k_exchange(XchgArgs a) {
     __shared__ double vals[32];
     const int tid = threadIdx.x;
     for (int i = tid >> 6; i < a.cnt; i += XBLOCK / 64) {
-        const double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
+        double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
+        if (a.rank != 0 && !((a.keepmask >> i) & 1u)) t = 0.0;
         if ((tid & 63) == 0) vals[i] = t;
     }
     __syncthreads();
@@ -1032,7 +1035,8 @@ static __global__ void __launch_bounds__(XBLOCK) k_exchange_collect(XCollectArgs
     __shared__ double got[8][32];
     const int tid = threadIdx.x;
     for (int i = tid >> 6; i < a.cnt; i += XBLOCK / 64) {
-        const double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
+        double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
+        if (a.rank != 0 && !((a.keepmask >> i) & 1u)) t = 0.0;
         if ((tid & 63) == 0) vals[i] = t;
     }
     __syncthreads();
@@ -1110,11 +1114,50 @@ __global__ void __launch_bounds__(XBLOCK) k_halo_exchange(HaloArgs<T> a) {
     __threadfence_system();
 }
 
+// Row-sharded dense constraint (x replicated, the rows of A and the ny-vectors sharded): this rank's partial
+// of A' yhat (n values) goes into every rank's region, slot [parity][rank], through the IPC mapping; the caller
+// then sums the nranks partials in rank order (k_gemv_t_finish with the region as its chunk array), so all
+// ranks hold the same bits.  Same protocol as k_halo_exchange (plain stores, release, flag per source rank).
+template <class T> struct VecXchgArgs {
+    const T* local;                  // npad values
+    T* peer_slot[8];                 // every rank's region, this rank's slot of this parity
+    unsigned long long* peer_flag[8];
+    const unsigned long long* my_flags;      // [nranks] of this parity
+    unsigned long long seq;
+    int64_t npad;
+    int nranks;
+    int* timeout;
+};
+template <class T>
+__global__ void __launch_bounds__(XBLOCK) k_vec_allgather(VecXchgArgs<T> a) {
+    constexpr int N = PackN<T>::N;
+    const int64_t packs = a.npad / N;
+    for (int64_t c = threadIdx.x; c < packs; c += XBLOCK) {
+        const Pack<T> v = ld(a.local, c * N, N);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < a.nranks) st(a.peer_slot[r], c * N, N, v);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x < a.nranks) {
+        sys_store(a.peer_flag[threadIdx.x], a.seq);
+        unsigned spins = 0;
+        while (sys_load(a.my_flags + threadIdx.x) != a.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > XSPIN_LIMIT) { *a.timeout = 5; break; }
+        }
+    }
+    __threadfence_system();
+}
+
 // RCCL transport: fold this rank's block partials of slots [first, first+cnt) into the send buffer
 static __global__ void __launch_bounds__(XBLOCK)
-k_pack(const double* parts, SlotCounts counts, int first, int cnt, unsigned maxmask, double* send) {
+k_pack(const double* parts, SlotCounts counts, int first, int cnt, unsigned maxmask, double* send, int rank,
+       unsigned keepmask) {
     for (int i = threadIdx.x >> 6; i < cnt; i += XBLOCK / 64) {
-        const double t = fold_wave(parts + (size_t)(first + i) * PSTRIDE, counts.get(i), (maxmask >> i) & 1u);
+        double t = fold_wave(parts + (size_t)(first + i) * PSTRIDE, counts.get(i), (maxmask >> i) & 1u);
+        if (rank != 0 && !((keepmask >> i) & 1u)) t = 0.0;
         if ((threadIdx.x & 63) == 0) send[first + i] = t;
     }
 }

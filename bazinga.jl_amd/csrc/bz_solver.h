@@ -123,6 +123,8 @@ struct SolverBase {
     virtual void eval_lbfgs(int m, const void* S, const void* Y, const void* v, void* d) = 0;
     virtual void halo_export(void* handle64) = 0;
     virtual void halo_connect(const void* prev64, const void* next64) = 0;
+    virtual void allreduce_export(void* handle64) = 0;
+    virtual void allreduce_connect(const void* handles) = 0;
     virtual void profile_enable(unsigned mask) = 0;
     virtual void profile_get(int cat, int64_t* launches, double* ms) = 0;
     virtual void profile_reset() = 0;

@@ -105,8 +105,10 @@ template <class T> class Solver final : public SolverBase {
         if (d.c_kind == BZ_C_DENSE_AFFINE) {
             if (ny <= 0 || !d.c_A || !d.c_b) throw Error(BZ_ERR_ARG, "DenseAffine needs A[ny][n] and b[ny]");
             if (d.f_kind == BZ_F_STENCIL5) throw Error(BZ_ERR_UNSUPPORTED, "Stencil5pt f with a dense c");
-            if (ctx->nranks > 1)
-                throw Error(BZ_ERR_UNSUPPORTED, "DenseAffine is not sharded (needs an n-vector all-reduce)");
+            // nranks > 1: the ROWS of A (and b, mu, y: ny = this rank's rows) are sharded, x is replicated; the
+            // n-vector A' yhat is summed over the ranks through IPC-mapped regions (bz_problem_allreduce_*)
+            if (ctx->nranks > 1 && (!ctx->p2p_on || slack))
+                throw Error(BZ_ERR_UNSUPPORTED, "a row-sharded DenseAffine needs the p2p mailboxes and no slack");
         }
         if (d.f_kind < BZ_F_ZERO || d.f_kind > BZ_F_QUADRATIC)
             throw Error(BZ_ERR_UNSUPPORTED, "smooth-cost kind not lowered to the device");
@@ -188,6 +190,8 @@ template <class T> class Solver final : public SolverBase {
             CX_.alloc(ny); YU_.alloc(ny);
             plan_chunks(ny, rows_per_chunk, nrowchunks);
             GT_.alloc((size_t)nrowchunks * npad);
+            x_replicated = ctx->nranks > 1;
+            if (x_replicated) JL_.alloc(npad);
         }
 
         std::memset(&P, 0, sizeof(P));
@@ -252,6 +256,9 @@ template <class T> class Solver final : public SolverBase {
     ~Solver() override {
         for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto& e : ev_pool) (void)hipEventDestroy(e);
+        for (int r = 0; r < P2P_MAXRANKS; ++r)
+            if (ar_peer_[r] && ar_peer_[r] != ar_local_) (void)hipIpcCloseMemHandle(ar_peer_[r]);
+        if (ar_local_) (void)hipFree(ar_local_);
         if (halo_prev_) (void)hipIpcCloseMemHandle(halo_prev_);
         if (halo_next_) (void)hipIpcCloseMemHandle(halo_next_);
         if (halo_local_) (void)hipFree(halo_local_);
@@ -314,8 +321,7 @@ template <class T> class Solver final : public SolverBase {
 
     void eval_al_gradient(const void* x, void* dlx, double* vals3) override {
         copy_in(TMP_.p, x, n);
-        algrad(TMP_.p, D_.p, SL_AUX);
-        gather(SL_AUX, 2, 0u);
+        algrad(TMP_.p, D_.p, SL_AUX);           // (exchanges its two slots itself)
         auto v = collect({SL_AUX, SL_AUX + 1}, 0u);
         T half_pen = T(0.5) * T(v[1]);
         vals3[0] = (double)al_value(v[0], v[1]);
@@ -429,7 +435,7 @@ template <class T> class Solver final : public SolverBase {
             if (dense_c) eval_c(x);                                  // eval!(cx, c, x)  alps.jl:72
             launch(C_MISC, k_dual_update<T>, grid_y, dense_c ? (const T*)CX_.p : (const T*)x, P, ymul_.p, sproj_.p,
                    ny, parts_.p, (int)SL_OUTER);
-            gather(SL_OUTER, 1, 1u);
+            gather(SL_OUTER, 1, 1u, 1u);
             auto r = collect({SL_OUTER}, 1u);
             norm_res_prim_old = norm_res_prim; have_old = have_res;
             norm_res_prim = r[0]; have_res = true;
@@ -732,6 +738,64 @@ template <class T> class Solver final : public SolverBase {
         return StencilHalo<T>{halo_prev_ ? halo_row(halo_local_, par, 0, gny) : nullptr,
                               halo_next_ ? halo_row(halo_local_, par, 1, gny) : nullptr};
     }
+    // ---- row-sharded dense constraint: x replicated, A' yhat summed over the ranks --------------------
+    // region layout: slots[parity][rank][npad] of T, then flags[parity][rank]
+    bool x_replicated = false;
+    DBuf<T> JL_;                     // this rank's partial of A' yhat
+    void* ar_local_ = nullptr;
+    void* ar_peer_[P2P_MAXRANKS] = {};
+    bool ar_connected_ = false;
+    unsigned long long arseq_ = 0;
+    size_t ar_slots_bytes() const { return ((size_t)2 * ctx->nranks * npad * sizeof(T) + 63) / 64 * 64; }
+    size_t ar_bytes() const { return ar_slots_bytes() + 2 * P2P_MAXRANKS * sizeof(unsigned long long); }
+    T* ar_slot(void* base, int par, int r) const { return (T*)base + (size_t)(par * ctx->nranks + r) * npad; }
+    unsigned long long* ar_flag(void* base, int par, int r) const {
+        return (unsigned long long*)((char*)base + ar_slots_bytes()) + (par * P2P_MAXRANKS + r);
+    }
+   public:
+    void allreduce_export(void* handle64) override {
+        if (!x_replicated) throw Error(BZ_ERR_STATE, "all-reduce regions exist only for a row-sharded DenseAffine problem");
+        BZ_HIP(hipSetDevice(ctx->device));
+        if (!ar_local_) {
+            BZ_HIP(hipExtMallocWithFlags(&ar_local_, ar_bytes(), hipDeviceMallocFinegrained));
+            BZ_HIP(hipMemset(ar_local_, 0, ar_bytes()));
+            BZ_HIP(hipDeviceSynchronize());
+        }
+        hipIpcMemHandle_t h;
+        BZ_HIP(hipIpcGetMemHandle(&h, ar_local_));
+        std::memcpy(handle64, &h, sizeof(h));
+    }
+    void allreduce_connect(const void* handles) override {
+        if (!ar_local_) throw Error(BZ_ERR_STATE, "bz_problem_allreduce_export must be called first");
+        if (!handles) throw Error(BZ_ERR_ARG, "null handles");
+        BZ_HIP(hipSetDevice(ctx->device));
+        for (int r = 0; r < ctx->nranks; ++r) {
+            if (r == ctx->rank) { ar_peer_[r] = ar_local_; continue; }
+            if (ar_peer_[r]) continue;
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, (const char*)handles + (size_t)r * 64, 64);
+            BZ_HIP(hipIpcOpenMemHandle(&ar_peer_[r], h, hipIpcMemLazyEnablePeerAccess));
+        }
+        ar_connected_ = true;
+    }
+   private:
+    // sum JL_ over the ranks: returns the chunk array (nranks chunks of npad) k_gemv_t_finish then folds
+    const T* allreduce_partials() {
+        if (!ar_connected_) throw Error(BZ_ERR_STATE, "row-sharded DenseAffine: bz_problem_allreduce_connect has not been called");
+        const unsigned long long seq = ++arseq_;
+        const int par = (int)(seq & 1ull);
+        VecXchgArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        a.local = JL_.p; a.seq = seq; a.npad = npad; a.nranks = ctx->nranks; a.timeout = ptimeout_dev_;
+        for (int r = 0; r < ctx->nranks; ++r) {
+            a.peer_slot[r] = ar_slot(ar_peer_[r], par, ctx->rank);
+            a.peer_flag[r] = ar_flag(ar_peer_[r], par, ctx->rank);
+        }
+        a.my_flags = ar_flag(ar_local_, par, 0);
+        launch_b(C_GATHER, k_vec_allgather<T>, 1, XBLOCK, a);
+        return ar_slot(ar_local_, par, 0);
+    }
+
     void* halo_local_ = nullptr;
     void* halo_prev_ = nullptr;
     void* halo_next_ = nullptr;
@@ -739,8 +803,11 @@ template <class T> class Solver final : public SolverBase {
     unsigned long long hseq_ = 0;
 
     // multi-GPU: fold this rank's block partials of slots [first, first+cnt) and all-gather
-    void gather(int first, int cnt, unsigned maxmask) {
+    // ymask (row-sharded dense c only, where x-space quantities are computed in full by every rank): the
+    // slots that are sums over THIS rank's constraint rows and must be added up; the others count once
+    void gather(int first, int cnt, unsigned maxmask, unsigned ymask = 0u) {
         if (!ctx->multi()) return;
+        const unsigned keepmask = x_replicated ? ymask : ~0u;
         if (ctx->p2p_on) {
             if (cnt > P2P_PACK) throw Error(BZ_ERR_ARG, "pack too large for the p2p mailbox");
             XchgArgs a;
@@ -751,7 +818,7 @@ template <class T> class Solver final : public SolverBase {
             a.recv = recv_.p + (size_t)first * ctx->nranks;
             a.mbox_local = (P2PWords*)ctx->mbox_local;
             for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
-            a.timeout = ptimeout_dev_;
+            a.timeout = ptimeout_dev_; a.keepmask = keepmask;
             launch_b(C_GATHER, k_exchange, 1, XBLOCK, a);
             for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
             return;
@@ -760,7 +827,8 @@ template <class T> class Solver final : public SolverBase {
         SlotCounts counts;
         std::memset(&counts, 0, sizeof(counts));
         for (int i = 0; i < cnt; ++i) counts.set(i, slot_n[first + i]);
-        launch_b(C_GATHER, k_pack, 1, XBLOCK, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p);
+        launch_b(C_GATHER, k_pack, 1, XBLOCK, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p, ctx->rank,
+                 keepmask);
         BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
                               ctx->comm, ctx->stream));
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
@@ -777,7 +845,7 @@ template <class T> class Solver final : public SolverBase {
         a.recv = recv_.p + (size_t)first * ctx->nranks;
         a.mbox_local = (P2PWords*)ctx->mbox_local;
         for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
-        a.timeout = ptimeout_dev_;
+        a.timeout = ptimeout_dev_; a.keepmask = ~0u;
         b.host_out = host_out_dev_;
         b.ticket = ++collect_seq;
         launch_b(C_GATHER, k_exchange_collect, 1, XBLOCK, b);
@@ -840,6 +908,7 @@ template <class T> class Solver final : public SolverBase {
                         code == 1 ? "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)"
                         : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
                         : code == 4 ? "stencil halo exchange timed out waiting for a neighbour rank"
+                        : code == 5 ? "dense-constraint all-reduce timed out waiting for a peer rank"
                                     : "persistent two-loop kernel: p2p phase exchange timed out waiting for a peer rank");
         }
         std::vector<double> out(a.n);
@@ -934,8 +1003,18 @@ template <class T> class Solver final : public SolverBase {
             launch(C_MISC, k_yupd<T>, grid_y, (const T*)CX_.p, P, YU_.p, ny, parts_.p, slot0 + 1);
             slot_n[slot0] = grid; slot_n[slot0 + 1] = grid_y;
             gemv_cols(A_.p, ny, YU_.p, rows_per_chunk, nrowchunks);           // jtv = A' yupd (row-chunk partials)
-            launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, npad, x, P, grad, n, parts_.p, slot0);
-            gather(slot0, 2, 0u);
+            if (x_replicated) {
+                // this rank's rows only: fold the chunks, sum over the ranks (rank order), then finish
+                ElemParams<T> Pz = P;
+                Pz.f_kind = BZ_F_ZERO;
+                launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, npad, x, Pz, JL_.p, n, parts_.p,
+                       (int)SL_SCRATCH);
+                const T* chunks = allreduce_partials();
+                launch(C_MISC, k_gemv_t_finish<T>, grid, chunks, ctx->nranks, npad, x, P, grad, n, parts_.p, slot0);
+            } else {
+                launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, npad, x, P, grad, n, parts_.p, slot0);
+            }
+            gather(slot0, 2, 0u, 2u);         // slot0: f terms (x-space) ; slot0 + 1: penalty terms (this rank's rows)
             return;
         }
         slot_n[slot0] = slot_n[slot0 + 1] = grid;
@@ -985,7 +1064,7 @@ template <class T> class Solver final : public SolverBase {
     void aug_lag_update() {
         launch(C_MISC, k_muy<T>, grid_y, (const T*)mu_.p, (const T*)ymul_.p, muy_.p, ny, parts_.p,
                (int)SL_OUTER);
-        gather(SL_OUTER, 2, 2u);
+        gather(SL_OUTER, 2, 2u, 3u);
         auto v = collect({SL_OUTER, SL_OUTER + 1}, 2u);
         if (v[1] > 0.0) throw Error(BZ_ERR_MU, "parameters `mu` must be positive");
         musqy = T(0.5) * T(v[0]);
@@ -1235,7 +1314,7 @@ template <class T> class Solver final : public SolverBase {
             int64_t min_n = 300000;      // below this 2m short launches beat 2m-1 grid barriers (~5 us each)
             if (const char* e = getenv("BZ_PERSIST_MIN_N")) min_n = atoll(e);
             // with several ranks the phases need the p2p mailboxes (RCCL cannot be called from a kernel)
-            persist_ok = o.persist && (!ctx->multi() || ctx->p2p_on) && persist_kr > 0 && n >= min_n;
+            persist_ok = o.persist && (!ctx->multi() || ctx->p2p_on) && persist_kr > 0 && n >= min_n && !x_replicated;
             if (ctx->nranks > 1 && !ctx->multi())
                 throw Error(BZ_ERR_STATE, "nranks > 1 needs an RCCL communicator or connected p2p mailboxes");
         }

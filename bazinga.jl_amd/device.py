@@ -140,6 +140,17 @@ class Problem:
         b = C.create_string_buffer(nxt, 64) if nxt else None
         L.check(L.load().bz_problem_halo_connect(self._h, a, b))
 
+    def allreduce_export(self) -> bytes:
+        """Row-sharded DenseAffine: this rank's all-reduce region (64-byte IPC handle)."""
+        buf = C.create_string_buffer(64)
+        L.check(L.load().bz_problem_allreduce_export(self._h, buf))
+        return buf.raw
+
+    def allreduce_connect(self, handles):
+        """handles: every rank's 64-byte handle, in rank order."""
+        blob = C.create_string_buffer(b"".join(handles), 64 * len(handles))
+        L.check(L.load().bz_problem_allreduce_connect(self._h, blob))
+
     def panoc_step(self):
         L.check(L.load().bz_panoc_step(self._h))
 

@@ -151,6 +151,14 @@ void bz_problem_destroy(bz_problem* p);
 int bz_problem_halo_export(bz_problem* p, void* handle64);
 int bz_problem_halo_connect(bz_problem* p, const void* prev64, const void* next64);
 
+/* BZ_C_DENSE_AFFINE with the ROWS of A sharded over the ranks of a node (cfg 4): desc.ny,
+ * c_A, c_b, mu, y are this rank's rows; x (desc.n) is replicated on every rank, which does all n-vector
+ * work in full; the one n-vector that couples the ranks, A' yhat, is summed in rank order through
+ * IPC-mapped regions.  After bz_problem_create (mailboxes connected): export, all-gather the 64-byte
+ * handles (nranks * 64 bytes, rank order), connect.                                                   */
+int bz_problem_allreduce_export(bz_problem* p, void* handle64);
+int bz_problem_allreduce_connect(bz_problem* p, const void* handles);
+
 /* ---- inner solver: replaces  ProximalAlgorithms.PANOCplus(...)(f=alFun,g=gFun,x0=x)
  *      at src/algorithms/alps.jl:64-66 ------------------------------------------- */
 typedef struct {

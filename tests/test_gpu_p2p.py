@@ -239,3 +239,121 @@ def test_sharded_stencil_alps(bz):
     # (2e-6 in x), not the per-iterate 1e-10 of the test above
     assert np.max(np.abs(x - o[0])) <= 2e-5 * max(1.0, np.max(np.abs(o[0])))
     assert np.all(x >= d["psi"] - 1e-5)
+
+
+# ---------------------------------------------------------------- row-sharded dense constraint (cfg 4)
+DENSE = (96, 640)        # ny x n
+
+
+def _dense_problem(bz, dtype):
+    ny, n = DENSE
+    rng = np.random.default_rng(21)
+    A = (rng.standard_normal((ny, n)) / np.sqrt(ny)).astype(dtype)
+    xt = np.where(rng.uniform(size=n) < 0.05, rng.choice([-1.0, 1.0], n), 0.0).astype(dtype)
+    b = (A.astype(np.float64) @ xt.astype(np.float64)).astype(dtype)
+    return A, b
+
+
+def _dense_worker(rank, world, conn, mode, dtype_name):
+    try:
+        sys.path.insert(0, ROOT)
+        import bazinga_jl_amd as bz
+        dtype = np.dtype(dtype_name).type
+        ny, n = DENSE
+        A, b = _dense_problem(bz, dtype)
+        r0, r1 = _row_blocks(ny, world)[rank]
+        nyl = r1 - r0
+        ctx = bz.Context(device=0, rank=rank, nranks=world, comm_id=None)
+        conn.send(ctx.p2p_export())
+        ctx.p2p_connect(conn.recv(), [0] * world)
+        oracles = (bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(A[r0:r1], b[r0:r1]), bz.ZeroSet())
+        prob = bz.Problem(*oracles, n, nyl, dtype, ctx)
+        conn.send(prob.allreduce_export())
+        prob.allreduce_connect(conn.recv())
+        if mode == "panoc":
+            mu = np.full(nyl, 0.05, dtype)
+            y = np.cos(np.arange(r0, r1)).astype(dtype)
+            prob.set_multipliers(mu, y)
+            prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n, dtype))
+            for _ in range(ITERS):
+                prob.panoc_step()
+            out = (rank, prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars())
+            prob.close()
+        else:
+            r = bz.alps(*oracles, np.zeros(n, dtype), np.zeros(nyl, dtype), ctx=ctx, problem=prob,
+                        tol=dtype(1e-6 if dtype is np.float64 else 1e-4), verbose=bool(os.environ.get("BZ_TEST_VERBOSE")))
+            out = (rank, r[0], r[1], (r[2], r[3], r[5]))
+        ctx.close()
+        conn.send(("ok", out))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        conn.send(("error", repr(e) + traceback.format_exc()[-1500:]))
+
+
+def _run_dense(world, mode, dtype_name):
+    mpc = mp.get_context("spawn")
+    pipes = [mpc.Pipe() for _ in range(world)]
+    procs = [mpc.Process(target=_dense_worker, args=(r, world, pipes[r][1], mode, dtype_name)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for _round in range(2):                      # mailbox handles, then all-reduce region handles
+        hs = [pipes[r][0].recv() for r in range(world)]
+        for r in range(world):
+            pipes[r][0].send(hs)
+    res = []
+    for r in range(world):
+        assert pipes[r][0].poll(240), "rank did not answer"
+        status, payload = pipes[r][0].recv()
+        assert status == "ok", payload
+        res.append(payload)
+    for p in procs:
+        p.join(60)
+    return sorted(res)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,dtype_name", [(2, "float64"), (3, "float64"), (2, "float32")])
+def test_row_sharded_dense_constraint_matches_single_rank(bz, world, dtype_name):
+    """SURVEY §8(e)/(f-4), cfg 4 sharded: the rows of A (and b, mu, y) cut into blocks, x replicated; A' yhat
+    summed over the ranks in rank order through IPC-mapped regions; x-space scalars counted once, the
+    constraint-space ones added up.  Every rank must hold the SAME x (bit for bit) and it must equal the
+    single-rank iterate to the north-star tolerance (float32: a few ulps)."""
+    dtype = np.dtype(dtype_name).type
+    ny, n = DENSE
+    A, b = _dense_problem(bz, dtype)
+    prob = bz.Problem(bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(A, b), bz.ZeroSet(), n, ny, dtype)
+    prob.set_multipliers(np.full(ny, 0.05, dtype), np.cos(np.arange(ny)).astype(dtype))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n, dtype))
+    for _ in range(ITERS):
+        prob.panoc_step()
+    x1, z1, s1 = prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars()
+    prob.close()
+    res = _run_dense(world, "panoc", dtype_name)
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])     # replicas stay identical
+        for key in ("gamma", "f_x", "g_z", "stop_norm", "FBE"):
+            assert r[3][key] == res[0][3][key], f"ranks disagree on {key}"
+    tol = 1e-10 if dtype is np.float64 else 2e-4
+    assert abs(res[0][3]["gamma"] - s1["gamma"]) <= (1e-13 if dtype is np.float64 else 1e-5) * s1["gamma"]
+    assert np.max(np.abs(res[0][1] - x1)) <= tol * max(1e-30, np.max(np.abs(x1)))
+    assert np.max(np.abs(res[0][2] - z1)) <= tol * max(1e-30, np.max(np.abs(z1)))
+
+
+@pytest.mark.timeout(600)
+def test_row_sharded_dense_constraint_alps(bz):
+    """Whole ALPS solve of the basis-pursuit problem with the rows of A over two ranks."""
+    ny, n = DENSE
+    A, b = _dense_problem(bz, np.float64)
+    o = bz.alps(bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(A, b), bz.ZeroSet(), np.zeros(n), np.zeros(ny))
+    res = _run_dense(2, "alps", "float64")
+    assert np.array_equal(res[0][1], res[1][1])
+    y = np.concatenate([r[2] for r in res])
+    assert all(r[3][2] == o[5] == "first_order" for r in res)
+    # ~2000 inner iterations of a nonsmooth problem with tau backtracks: the two runs follow each other for the
+    # first ~70 iterations (the 1e-10 test above) and then take different, equally valid paths to the same
+    # solution — counts agree loosely, the solutions to the solver's tolerance
+    assert all(abs(r[3][0] - o[2]) <= 3 and abs(r[3][1] - o[3]) <= 0.25 * o[3] for r in res)
+    assert np.max(np.abs(res[0][1] - o[0])) <= 5e-4 * max(1.0, np.max(np.abs(o[0])))
+    assert np.array_equal(np.abs(res[0][1]) > 1e-3, np.abs(o[0]) > 1e-3)          # same support
+    assert np.max(np.abs(A @ res[0][1] - b)) <= 1e-5
+    assert y.shape == o[1].shape

@@ -994,10 +994,18 @@ __device__ __forceinline__ void host_post(double* out, int i, double v, unsigned
 static __global__ void __launch_bounds__(XBLOCK) k_exchange(XchgArgs a) {
     __shared__ double vals[32];
     const int tid = threadIdx.x;
-    for (int i = tid >> 6; i < a.cnt; i += XBLOCK / 64) {
-        double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
-        if (a.rank != 0 && !((a.keepmask >> i) & 1u)) t = 0.0;
-        if ((tid & 63) == 0) vals[i] = t;
+    {   // 16 waves, up to 32 slots: every wave folds slots w and w + 16 in ONE pass (their loads are issued
+        // together; a slot beyond cnt folds zero partials)
+        const int i0 = tid >> 6, i1 = i0 + XBLOCK / 64;
+        const int c0 = i0 < a.cnt ? a.counts.get(i0) : 0, c1 = i1 < a.cnt ? a.counts.get(i1) : 0;
+        double t0 = fold_wave(a.parts + (size_t)(a.first + i0) * PSTRIDE, c0, (a.maxmask >> i0) & 1u);
+        double t1 = fold_wave(a.parts + (size_t)(a.first + (i1 < a.cnt ? i1 : i0)) * PSTRIDE, c1, (a.maxmask >> (i1 & 31)) & 1u);
+        if (a.rank != 0 && !((a.keepmask >> i0) & 1u)) t0 = 0.0;
+        if (a.rank != 0 && !((a.keepmask >> (i1 & 31)) & 1u)) t1 = 0.0;
+        if ((tid & 63) == 0) {
+            if (i0 < a.cnt) vals[i0] = t0;
+            if (i1 < a.cnt) vals[i1] = t1;
+        }
     }
     __syncthreads();
     const int par = (int)(a.seq & 1ull);
@@ -1034,10 +1042,18 @@ static __global__ void __launch_bounds__(XBLOCK) k_exchange_collect(XCollectArgs
     __shared__ double vals[32];
     __shared__ double got[8][32];
     const int tid = threadIdx.x;
-    for (int i = tid >> 6; i < a.cnt; i += XBLOCK / 64) {
-        double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
-        if (a.rank != 0 && !((a.keepmask >> i) & 1u)) t = 0.0;
-        if ((tid & 63) == 0) vals[i] = t;
+    {   // 16 waves, up to 32 slots: every wave folds slots w and w + 16 in ONE pass (their loads are issued
+        // together; a slot beyond cnt folds zero partials)
+        const int i0 = tid >> 6, i1 = i0 + XBLOCK / 64;
+        const int c0 = i0 < a.cnt ? a.counts.get(i0) : 0, c1 = i1 < a.cnt ? a.counts.get(i1) : 0;
+        double t0 = fold_wave(a.parts + (size_t)(a.first + i0) * PSTRIDE, c0, (a.maxmask >> i0) & 1u);
+        double t1 = fold_wave(a.parts + (size_t)(a.first + (i1 < a.cnt ? i1 : i0)) * PSTRIDE, c1, (a.maxmask >> (i1 & 31)) & 1u);
+        if (a.rank != 0 && !((a.keepmask >> i0) & 1u)) t0 = 0.0;
+        if (a.rank != 0 && !((a.keepmask >> (i1 & 31)) & 1u)) t1 = 0.0;
+        if ((tid & 63) == 0) {
+            if (i0 < a.cnt) vals[i0] = t0;
+            if (i1 < a.cnt) vals[i1] = t1;
+        }
     }
     __syncthreads();
     const int par = (int)(a.seq & 1ull);

@@ -928,3 +928,30 @@ def test_device_matches_golden_fixtures(bz, ref):
         a = bz.alps(*dev, np.zeros(n), np.zeros(n))
         assert a[5] == g["status"] and a[2] == g["tot_it"] and abs(a[3] - g["tot_inner_it"]) <= 2, kind
         assert rel(a[0], np.array(g["x"])) <= 1e-8, kind
+
+
+def test_headline_size_compact_form_matches_two_loop_oracle(bz, ref):
+    """What bench.py times (n = 10^7, compact L-BFGS representation, the compile-time-specialised one-pass
+    kernel with non-temporal streams) against the numpy oracle in the REFERENCE's two-loop form: the first
+    states of the exact benchmark problem agree within the north-star tolerance, and the kernel that ran
+    is the fused one."""
+    n = 10_000_000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
+    mg = float(np.finfo(float).eps)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=mg, directions=bz.LBFGS(5, compact=True)).c_opts(), x0)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
+    it = ref.PANOCplusIteration(al, ref.NonsmoothCostFun(orc[1]), x0, minimum_gamma=mg)
+    st = it.init()
+    for k in range(9):
+        sc = prob.panoc_scalars()
+        assert abs(sc["gamma"] - float(st.gamma)) <= 1e-13 * float(st.gamma)
+        ex, ez = rel(prob.panoc_vector("x"), st.x), rel(prob.panoc_vector("z"), st.z)
+        assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k + 1}: {ex} {ez}"
+        if k < 8:
+            prob.panoc_step()
+            st = it.step(st)
+    assert prob.panoc_stats().n_fused_iters >= 7 and int(prob.panoc_scalars()["lbfgs_mem"]) == 5
+    prob.close()

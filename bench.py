@@ -53,7 +53,9 @@ def cpu_baseline(n, states):
     out = {"value": round((states - 1) / dt, 4), "unit": "iterations/s", "cores": 1, "kind": "port",
            "sample": f"first {states - 1} PANOCplus iterations (plus the initial state) of the same n={n} "
                      f"workload, oracle/c/bz_oracle.c, single thread, {dt:.1f} s",
-           "host_cpus": os.cpu_count()}
+           "host_cpus": os.cpu_count(),
+           # the real reference would be timed here if the box had Julia + ProximalAlgorithms
+           "julia_on_box": __import__("shutil").which("julia") is not None}
     try:
         threads = int(os.environ.get("BZ_BENCH_CPU_THREADS", "0")) or min(16, len(os.sched_getaffinity(0)))
         os.environ["OMP_NUM_THREADS"] = str(threads)

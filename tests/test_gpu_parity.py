@@ -969,3 +969,28 @@ def test_headline_size_compact_form_matches_two_loop_oracle(bz, ref):
             st = it.step(st)
     assert prob.panoc_stats().n_fused_iters >= 7 and int(prob.panoc_scalars()["lbfgs_mem"]) == 5
     prob.close()
+
+
+def test_alps_termination_statuses(bz, ref):
+    """alps.jl:87-90,105-113: `:max_iter` when the outer budget runs out, `:exception` when the objective turns
+    NaN — same status, counts and (for max_iter) point as the oracle; resident and host outer loops alike."""
+    import warnings
+    n = 2000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    for maxit in (1, 2):
+        o = ref.alps(*orc, x0, y0, maxit=maxit)
+        for resident in (True, False):
+            a = bz.alps(*dev, x0, y0, maxit=maxit, resident=resident)
+            assert a[5] == o[5] == "max_iter" and a[2] == o[2] == maxit and a[3] == o[3]
+            assert rel(a[0], o[0]) <= 1e-9 and rel(a[1], o[1]) <= 1e-8
+    # NaN in the data: objective NaN after the first subproblem -> :exception (alps.jl:89,109)
+    bn = d["b"].copy()
+    bn[7] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = ref.alps(ref.DiagQuadratic(d["q"], bn), orc[1], orc[2], orc[3], x0, y0, maxit=5, subsolver_maxit=50,
+                     subsolver=lambda **kw: ref.PANOCplus(maxit=50, **kw))
+    a = bz.alps(bz.DiagQuadratic(d["q"], bn), dev[1], dev[2], dev[3], x0, y0, maxit=5, subsolver_maxit=50,
+                subsolver=lambda **kw: bz.PANOCplus(maxit=50, **kw), resident=True)
+    assert o[5] == "exception" and a[5] == "exception" and a[2] == o[2]

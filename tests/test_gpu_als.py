@@ -101,3 +101,21 @@ def test_als_rejects_unsupported(bz, ref):
         prob.alps_solve(ao, po, np.zeros(n), np.zeros(n))
     prob.slack = False
     prob.close()
+
+
+def test_als_with_compact_lbfgs_and_no_acceleration(bz, ref):
+    """The slack path has no fused kernel: with the compact L-BFGS form every iteration takes the generic
+    route (k_gram_dots + read-back for p, w; k_compact_xd for x_d).  Same minimiser as the oracle's ALS; and
+    `NoAcceleration` (demo/rosenbrock.jl:96-97) on the slack problem as well."""
+    n = 2000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    o = ref.als(*orc, x0, y0)
+    a = bz.als(*dev, x0, y0, subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(5, compact=True), **kw), resident=True)
+    assert a[5] == o[5] == "first_order" and a[2] == o[2]
+    assert abs(a[3] - o[3]) <= max(3, 0.1 * o[3])
+    assert rel(a[0], o[0]) <= 1e-6
+    o2 = ref.als(*orc, x0, y0, subsolver=lambda **kw: ref.PANOCplus(directions=ref.NoAcceleration(), **kw))
+    a2 = bz.als(*dev, x0, y0, subsolver=lambda **kw: bz.PANOCplus(directions=bz.NoAcceleration(), **kw), resident=True)
+    assert a2[5] == o2[5] and a2[2] == o2[2] and abs(a2[3] - o2[3]) <= max(3, 0.1 * o2[3])
+    assert rel(a2[0], o2[0]) <= 1e-6

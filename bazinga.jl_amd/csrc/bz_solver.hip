@@ -819,7 +819,7 @@ template <class T> class Solver final : public SolverBase {
             a.mbox_local = (P2PWords*)ctx->mbox_local;
             for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
             a.timeout = ptimeout_dev_; a.keepmask = keepmask;
-            launch_b(C_GATHER, k_exchange, 1, XBLOCK, a);
+            launch_b(C_GATHER, k_exchange, cnt, BLOCK, a);
             for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
             return;
         }
@@ -827,7 +827,7 @@ template <class T> class Solver final : public SolverBase {
         SlotCounts counts;
         std::memset(&counts, 0, sizeof(counts));
         for (int i = 0; i < cnt; ++i) counts.set(i, slot_n[first + i]);
-        launch_b(C_GATHER, k_pack, 1, XBLOCK, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p, ctx->rank,
+        launch_b(C_GATHER, k_pack, cnt, BLOCK, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p, ctx->rank,
                  keepmask);
         BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
                               ctx->comm, ctx->stream));
@@ -848,7 +848,7 @@ template <class T> class Solver final : public SolverBase {
         a.timeout = ptimeout_dev_; a.keepmask = ~0u;
         b.host_out = host_out_dev_;
         b.ticket = ++collect_seq;
-        launch_b(C_GATHER, k_exchange_collect, 1, XBLOCK, b);
+        launch_b(C_GATHER, k_exchange_collect, cnt, BLOCK, b);
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
         return b.ticket;
     }

@@ -16,6 +16,9 @@ ctx = None
 if os.environ.get("QB_XCHG") == "p2p":
     ctx = bz.Context(device=0, rank=0, nranks=1)
     ctx.p2p_connect([ctx.p2p_export()], [0])
+elif os.environ.get("QB_XCHG") == "p2p_unused":      # mailbox allocated and mapped, problem on the default context
+    _c2 = bz.Context(device=0, rank=0, nranks=1)
+    _c2.p2p_connect([_c2.p2p_export()], [0])
 elif os.environ.get("QB_XCHG") == "rccl":
     ctx = bz.Context(device=0, rank=0, nranks=1, comm_id=bz.Context.unique_id())
 prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),

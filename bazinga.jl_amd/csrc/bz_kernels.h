@@ -1122,19 +1122,32 @@ template <class T> struct VecXchgArgs {
     int64_t npad;
     int nranks;
     int* timeout;
+    unsigned long long* done;        // monotonic arrival counter of this kernel's workgroups
+    unsigned long long target;       // its value once every workgroup of THIS launch has arrived
 };
+// Many workgroups copy (2 MB per exchange at cfg-4 sizes is too much for one); each drains its stores with a
+// system-scope release and arrives at a counter; the workgroup that arrives last raises the flags at the
+// peers and waits for the flags this rank is owed, so the kernel ends exactly when the exchange is complete.
 template <class T>
-__global__ void __launch_bounds__(XBLOCK) k_vec_allgather(VecXchgArgs<T> a) {
+__global__ void __launch_bounds__(BLOCK) k_vec_allgather(VecXchgArgs<T> a) {
     constexpr int N = PackN<T>::N;
+    __shared__ int sh_last;
     const int64_t packs = a.npad / N;
-    for (int64_t c = threadIdx.x; c < packs; c += XBLOCK) {
+    for (int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x; c < packs; c += (int64_t)gridDim.x * BLOCK) {
         const Pack<T> v = ld(a.local, c * N, N);
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             if (r < a.nranks) st(a.peer_slot[r], c * N, N, v);
     }
-    __threadfence_system();
+    __threadfence_system();          // every storing lane: its rows before its arrival
     __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long old = __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = (old + 1ull == a.target) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __threadfence_system();
     if (threadIdx.x < a.nranks) {
         sys_store(a.peer_flag[threadIdx.x], a.seq);
         unsigned spins = 0;

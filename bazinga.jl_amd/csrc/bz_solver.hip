@@ -745,6 +745,8 @@ template <class T> class Solver final : public SolverBase {
     void* ar_local_ = nullptr;
     void* ar_peer_[P2P_MAXRANKS] = {};
     bool ar_connected_ = false;
+    DBuf<unsigned long long> ar_done_;
+    unsigned long long ar_done_base_ = 0;
     unsigned long long arseq_ = 0;
     size_t ar_slots_bytes() const { return ((size_t)2 * ctx->nranks * npad * sizeof(T) + 63) / 64 * 64; }
     size_t ar_bytes() const { return ar_slots_bytes() + 2 * P2P_MAXRANKS * sizeof(unsigned long long); }
@@ -792,7 +794,12 @@ template <class T> class Solver final : public SolverBase {
             a.peer_flag[r] = ar_flag(ar_peer_[r], par, ctx->rank);
         }
         a.my_flags = ar_flag(ar_local_, par, 0);
-        launch_b(C_GATHER, k_vec_allgather<T>, 1, XBLOCK, a);
+        const int64_t packs = npad / PackN<T>::N;
+        const int g = (int)std::max<int64_t>(1, std::min<int64_t>(64, (packs + BLOCK - 1) / BLOCK));
+        if (!ar_done_.p) ar_done_.alloc(16);
+        ar_done_base_ += (unsigned long long)g;
+        a.done = ar_done_.p; a.target = ar_done_base_;
+        launch_b(C_GATHER, k_vec_allgather<T>, g, BLOCK, a);
         return ar_slot(ar_local_, par, 0);
     }
 

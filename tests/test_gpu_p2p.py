@@ -243,10 +243,11 @@ def test_sharded_stencil_alps(bz):
 
 # ---------------------------------------------------------------- row-sharded dense constraint (cfg 4)
 DENSE = (96, 640)        # ny x n
+DENSE_WIDE = (64, 40000)  # n large enough for the all-gather of A'y to run on many workgroups
 
 
-def _dense_problem(bz, dtype):
-    ny, n = DENSE
+def _dense_problem(bz, dtype, shape=None):
+    ny, n = shape or DENSE
     rng = np.random.default_rng(21)
     A = (rng.standard_normal((ny, n)) / np.sqrt(ny)).astype(dtype)
     xt = np.where(rng.uniform(size=n) < 0.05, rng.choice([-1.0, 1.0], n), 0.0).astype(dtype)
@@ -254,13 +255,13 @@ def _dense_problem(bz, dtype):
     return A, b
 
 
-def _dense_worker(rank, world, conn, mode, dtype_name):
+def _dense_worker(rank, world, conn, mode, dtype_name, shape=None):
     try:
         sys.path.insert(0, ROOT)
         import bazinga_jl_amd as bz
         dtype = np.dtype(dtype_name).type
-        ny, n = DENSE
-        A, b = _dense_problem(bz, dtype)
+        ny, n = shape or DENSE
+        A, b = _dense_problem(bz, dtype, shape)
         r0, r1 = _row_blocks(ny, world)[rank]
         nyl = r1 - r0
         ctx = bz.Context(device=0, rank=rank, nranks=world, comm_id=None)
@@ -290,10 +291,10 @@ def _dense_worker(rank, world, conn, mode, dtype_name):
         conn.send(("error", repr(e) + traceback.format_exc()[-1500:]))
 
 
-def _run_dense(world, mode, dtype_name):
+def _run_dense(world, mode, dtype_name, shape=None):
     mpc = mp.get_context("spawn")
     pipes = [mpc.Pipe() for _ in range(world)]
-    procs = [mpc.Process(target=_dense_worker, args=(r, world, pipes[r][1], mode, dtype_name)) for r in range(world)]
+    procs = [mpc.Process(target=_dense_worker, args=(r, world, pipes[r][1], mode, dtype_name, shape)) for r in range(world)]
     for p in procs:
         p.start()
     for _round in range(2):                      # mailbox handles, then all-reduce region handles
@@ -312,15 +313,16 @@ def _run_dense(world, mode, dtype_name):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,dtype_name", [(2, "float64"), (3, "float64"), (2, "float32")])
-def test_row_sharded_dense_constraint_matches_single_rank(bz, world, dtype_name):
+@pytest.mark.parametrize("world,dtype_name,shape", [(2, "float64", None), (3, "float64", None), (2, "float32", None),
+                                                    (2, "float64", DENSE_WIDE)])
+def test_row_sharded_dense_constraint_matches_single_rank(bz, world, dtype_name, shape):
     """SURVEY §8(e)/(f-4), cfg 4 sharded: the rows of A (and b, mu, y) cut into blocks, x replicated; A' yhat
     summed over the ranks in rank order through IPC-mapped regions; x-space scalars counted once, the
     constraint-space ones added up.  Every rank must hold the SAME x (bit for bit) and it must equal the
     single-rank iterate to the north-star tolerance (float32: a few ulps)."""
     dtype = np.dtype(dtype_name).type
-    ny, n = DENSE
-    A, b = _dense_problem(bz, dtype)
+    ny, n = shape or DENSE
+    A, b = _dense_problem(bz, dtype, shape)
     prob = bz.Problem(bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(A, b), bz.ZeroSet(), n, ny, dtype)
     prob.set_multipliers(np.full(ny, 0.05, dtype), np.cos(np.arange(ny)).astype(dtype))
     prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n, dtype))
@@ -328,7 +330,7 @@ def test_row_sharded_dense_constraint_matches_single_rank(bz, world, dtype_name)
         prob.panoc_step()
     x1, z1, s1 = prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars()
     prob.close()
-    res = _run_dense(world, "panoc", dtype_name)
+    res = _run_dense(world, "panoc", dtype_name, shape)
     for r in res[1:]:
         assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])     # replicas stay identical
         for key in ("gamma", "f_x", "g_z", "stop_norm", "FBE"):

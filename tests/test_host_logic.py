@@ -53,6 +53,34 @@ def test_lowering_kinds(bz):
     assert d.g_kind == L.BZ_G_IND_BOX and d.g_lo_vec and not d.g_hi_vec and d.g_hi == 2.0
 
 
+def test_lowering_of_the_next_row_kinds(bz):
+    """pairwise sets, L0 / Lp oracles, stencil and dense operands, the slack flag."""
+    from bazinga_jl_amd.oracles import lower
+    L = bz._lib
+    n = 8
+    for kind, code in (("vc", L.BZ_D_VC_PAIRS), ("cc", L.BZ_D_CC_PAIRS), ("eitheror", L.BZ_D_EITHEROR_PAIRS),
+                       ("xor", L.BZ_D_XOR_PAIRS)):
+        d, _ = lower(bz.Zero(), bz.Zero(), bz.IdentityFunction(), bz.PairwiseSet(kind), n, n, np.float64)
+        assert d.D_kind == code
+    assert bz.VanishingConstraintPairs().kind == "vc" and bz.XorPairs().kind == "xor"
+    with pytest.raises(ValueError):
+        bz.PairwiseSet("nand")
+    with pytest.raises(ValueError):
+        lower(bz.Zero(), bz.Zero(), bz.IdentityFunction(), bz.PairwiseSet("cc"), 7, 7, np.float64)     # odd ny
+    u = np.linspace(0.0, 1.0, n)
+    d, _ = lower(bz.Zero(), bz.NormL0Box(0.3, u=u), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float64)
+    assert d.g_kind == L.BZ_G_NORM_L0_BOX and d.g_lambda == 0.3 and d.g_u
+    d, _ = lower(bz.Zero(), bz.NormLpPowerBox(0.5, 0.8, u=u), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float64)
+    assert d.g_kind == L.BZ_G_NORM_LP_BOX and d.g_p == 0.5 and d.g_lambda == 0.8
+    d, _ = lower(bz.Stencil5ptQuadratic(2, 4, np.ones(n)), bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float64)
+    assert d.f_kind == L.BZ_F_STENCIL5 and (d.f_grid_nx, d.f_grid_ny) == (2, 4)
+    A = np.ones((3, n), np.float32)
+    d, _ = lower(bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(A, np.zeros(3, np.float32)), bz.ZeroSet(), n, 3, np.float32)
+    assert d.c_kind == L.BZ_C_DENSE_AFFINE and d.ny == 3 and d.c_A and d.c_b
+    d, _ = lower(bz.Zero(), bz.Zero(), bz.IdentityFunction(), bz.FreeSet(), n, n, np.float64, slack=True)
+    assert d.slack == 1
+
+
 def test_unsupported_oracles_raise(bz):
     from bazinga_jl_amd.oracles import lower
 

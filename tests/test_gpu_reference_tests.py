@@ -5,6 +5,8 @@ Each test mirrors the Julia test line by line — same data, same call, same ass
     test/problems/test_verbose.jl        -> test_verbose_lasso
     test/problems/test_nonconvex_qp.jl   -> test_nonconvex_qp_tiny / _small
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -97,3 +99,25 @@ def test_dense_f_gradients_match_oracle(bz, ref):
             assert abs(vals[0] - lx) <= 1e-12 * max(1.0, abs(lx))
             assert abs(vals[1] - al.fx) <= 1e-12 * max(1.0, abs(al.fx))
             prob.close()
+
+
+def test_plain_c_caller_of_the_abi(bz):
+    """examples/panoc_capi.c: the boundary used from plain C — compiled here with gcc against
+    include/bazinga_hip.h, linked to the shared library, run as its own process.  It must solve cfg 2 with
+    the same outer / inner iteration counts as the Python harness does on the same splitmix64 data."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "panoc_capi")
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "panoc_capi"], check=True, capture_output=True)
+    n = 200_000
+    r = subprocess.run([exe, str(n), "50", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"alps: status (\d+)\s+outer (\d+)\s+inner (\d+)", r.stdout)
+    assert m and "iterations/s" in r.stdout, r.stdout
+    d = bz.synth.l1_quadratic(n)
+    out = bz.alps(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                  bz.ClosedSet(bz.IndBox(-1.0, 1.0)), np.zeros(n), np.zeros(n),
+                  subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(5, compact=True), **kw), resident=True)
+    assert int(m.group(1)) == 0 and out[5] == "first_order"
+    assert int(m.group(2)) == out[2] and int(m.group(3)) == out[3]

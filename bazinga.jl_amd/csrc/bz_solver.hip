@@ -1434,10 +1434,11 @@ template <class T> class Solver final : public SolverBase {
             static const int gfc_mult = std::getenv("BZ_GFC") ? std::atoi(std::getenv("BZ_GFC")) : 2;
             const int gfc = std::min(grid, gfc_mult * std::max(1, num_cus));
             for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
-            // non-temporal loads/stores once the working set is far beyond the Infinity Cache (measured +2.5 %
-            // at n = 10^7, -9 % at n = 1.25*10^6 where the 21 vectors fit)
+            // non-temporal loads/stores once the working set (2M + 11 vectors) no longer fits the 256 MB Infinity
+            // Cache.  Measured fused-pass times, default policy vs non-temporal: n = 1.25e6 (210 MB) 39.0 / 44.5 us,
+            // 1.8e6 (302 MB) 51.0 / 60.4, 2.5e6 (420 MB) 90.1 / 81.5, 5e6 (840 MB) 171 / 159, 1e7 322 / 314.
             static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
-            const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * (2 * CM + 11) > 600e6;
+            const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * (2 * CM + 11) > 360e6;
             // headline family with everything uniform fixed at compile time (see the kernel)
             static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
             const bool spec = spec_env && desc.f_kind == BZ_F_DIAG_QUADRATIC && desc.g_kind == BZ_G_NORM_L1 &&

@@ -994,3 +994,22 @@ def test_alps_termination_statuses(bz, ref):
     a = bz.alps(bz.DiagQuadratic(d["q"], bn), dev[1], dev[2], dev[3], x0, y0, maxit=5, subsolver_maxit=50,
                 subsolver=lambda **kw: bz.PANOCplus(maxit=50, **kw), resident=True)
     assert o[5] == "exception" and a[5] == "exception" and a[2] == o[2]
+
+
+@pytest.mark.timeout(900)
+def test_config5_size_closed_form(bz, ref):
+    """BASELINE config 5 size (n = 10^8, one GPU's worth of HBM: 21 vectors of 800 MB in flight): the
+    size-independent closed form of the D = FreeSet variant, x_i = soft(b_i, lambda) / q_i, through the whole
+    ALPS solve in both evaluations of the L-BFGS operator; x0 is not mutated."""
+    n = 100_000_000
+    d = bz.synth.l1_quadratic(n)
+    xs = np.sign(d["b"]) * np.maximum(np.abs(d["b"]) - d["lam"], 0) / d["q"]
+    x0, y0 = np.zeros(n), np.zeros(n)
+    for compact in (True, False):
+        out = bz.alps(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(), bz.FreeSet(), x0, y0,
+                      tol=1e-8, subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(5, compact=compact), **kw),
+                      resident=True)
+        assert out[5] == "first_order"
+        assert np.max(np.abs(out[0] - xs)) <= 1e-6
+        del out
+    assert not np.any(x0)

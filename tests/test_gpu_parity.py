@@ -1012,4 +1012,17 @@ def test_config5_size_closed_form(bz, ref):
         assert out[5] == "first_order"
         assert np.max(np.abs(out[0] - xs)) <= 1e-6
         del out
+    del xs
+    # the config itself (D = Box[-1,1], multipliers in play): feasibility and the KKT system of
+    # min f + g  s.t. x in [-1,1]:  0 in q x - b + y + lam sign(x)   (as test_full_size_properties at 10^7)
+    out = bz.alps(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                  bz.ClosedSet(bz.IndBox(-1.0, 1.0)), x0, y0,
+                  subsolver=lambda **kw: bz.PANOCplus(directions=bz.LBFGS(5, compact=True), **kw), resident=True)
+    x, y = out[0], out[1]
+    assert out[5] == "first_order"
+    assert np.max(np.abs(x - np.clip(x, -1, 1))) <= 1e-6
+    r = d["q"] * x - d["b"] + y
+    viol = np.where(x > 1e-9, np.abs(r + d["lam"]), np.where(x < -1e-9, np.abs(r - d["lam"]),
+                    np.maximum(np.abs(r) - d["lam"], 0)))
+    assert np.max(viol) <= 1e-4
     assert not np.any(x0)

@@ -1028,16 +1028,15 @@ struct XCollectArgs {
 // rank's copy, fold over the ranks, hand the total to the host.  The 32 scalars of an exchange travel
 // independently — every tagged word validates itself — so nothing serialises on one workgroup (a single
 // 1024-thread block doing all of it measured 9.6 us and delayed the host's view of the result by ~10 us more).
-static __global__ void __launch_bounds__(BLOCK) k_exchange_collect(XCollectArgs b) {
+static __global__ void __launch_bounds__(64) k_exchange_collect(XCollectArgs b) {      // one WAVE per scalar
     const XchgArgs& a = b.x;
-    __shared__ double sh[WAVES];
-    __shared__ double got[8];
     const int tid = threadIdx.x, i = blockIdx.x;
     const bool ismax = (a.maxmask >> i) & 1u;
-    double t = fold_src(ScalarSrc{a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), 1}, ismax, sh);
+    double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), ismax);
     if (a.rank != 0 && !((a.keepmask >> i) & 1u)) t = 0.0;
     const int par = (int)(a.seq & 1ull);
     const unsigned long long tag = (unsigned long long)ll_tag(a.seq) << 32;
+    double v = 0.0;
     if (tid < a.nranks) {
         const int r = tid;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
@@ -1054,16 +1053,16 @@ static __global__ void __launch_bounds__(BLOCK) k_exchange_collect(XCollectArgs 
             __builtin_amdgcn_s_sleep(1);
             if (++spins > XSPIN_LIMIT) { *a.timeout = 2; break; }
         }
-        const double v = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
-        got[r] = v;
+        v = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
         a.recv[r * a.cnt + i] = v;
     }
-    __syncthreads();
-    if (tid == 0) {
-        double g = 0.0;
-        for (int r = 0; r < a.nranks; ++r) g = ismax ? nanmax(g, got[r]) : g + got[r];
-        host_post(b.host_out, i, g, b.ticket);
+    // fold over the ranks in rank order (lane r holds rank r's copy): every lane computes the same chain
+    double g = 0.0;
+    for (int r = 0; r < a.nranks; ++r) {
+        const double vr = __shfl(v, r, 64);
+        g = ismax ? nanmax(g, vr) : g + vr;
     }
+    if (tid == 0) host_post(b.host_out, i, g, b.ticket);
 }
 
 // Halo exchange of the row-block-sharded stencil: this rank's first grid row goes to the previous rank's

@@ -82,6 +82,14 @@ __global__ void __launch_bounds__(BLOCK) k_collect(CollectArgs a, double* out) {
     if (threadIdx.x == 0) host_post(out, i, t, a.ticket);
 }
 
+// the same for unit-stride sources with ONE wave per scalar (fold_wave gives fold_src's bits): a 64-thread
+// workgroup needs no LDS and no barrier
+__global__ void __launch_bounds__(64) k_collect_w(CollectArgs a, double* out) {
+    const int i = blockIdx.x;
+    const double t = fold_wave(a.src[i].p, a.src[i].count, (a.maxmask >> i) & 1u);
+    if (threadIdx.x == 0) host_post(out, i, t, a.ticket);
+}
+
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
                  C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11 };
 
@@ -855,7 +863,7 @@ template <class T> class Solver final : public SolverBase {
         a.timeout = ptimeout_dev_; a.keepmask = ~0u;
         b.host_out = host_out_dev_;
         b.ticket = ++collect_seq;
-        launch_b(C_GATHER, k_exchange_collect, cnt, BLOCK, b);
+        launch_b(C_GATHER, k_exchange_collect, cnt, 64, b);
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
         return b.ticket;
     }
@@ -882,7 +890,11 @@ template <class T> class Solver final : public SolverBase {
     }
     std::vector<double> collect_run(CollectArgs& a) {
         a.ticket = ++collect_seq;
-        launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
+        static const int wave_env = std::getenv("BZ_COLLECT_WAVE") ? std::atoi(std::getenv("BZ_COLLECT_WAVE")) : 1;
+        bool unit = wave_env != 0;
+        for (int i = 0; i < a.n; ++i) unit = unit && a.src[i].stride == 1;
+        if (unit) launch_b(C_COLLECT, k_collect_w, a.n, 64, a, host_out_dev_);
+        else launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
         return wait_host(a.n, a.ticket);
     }
     // read n scalars from the pinned mailbox once both tagged words of each carry this read-back's tag

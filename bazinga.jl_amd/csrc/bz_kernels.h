@@ -991,10 +991,9 @@ __device__ __forceinline__ void host_post(double* out, int i, double v, unsigned
     sys_store(dst + 0, tag | (bits & 0xFFFFFFFFull));
     sys_store(dst + 1, tag | (bits >> 32));
 }
-static __global__ void __launch_bounds__(BLOCK) k_exchange(XchgArgs a) {      // one workgroup per slot
-    __shared__ double sh[WAVES];
+static __global__ void __launch_bounds__(64) k_exchange(XchgArgs a) {      // one wave per slot
     const int tid = threadIdx.x, i = blockIdx.x;
-    double t = fold_src(ScalarSrc{a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), 1}, (a.maxmask >> i) & 1u, sh);
+    double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), (a.maxmask >> i) & 1u);
     if (a.rank != 0 && !((a.keepmask >> i) & 1u)) t = 0.0;
     const int par = (int)(a.seq & 1ull);
     const unsigned long long tag = (unsigned long long)ll_tag(a.seq) << 32;
@@ -1159,13 +1158,12 @@ __global__ void __launch_bounds__(BLOCK) k_vec_allgather(VecXchgArgs<T> a) {
 }
 
 // RCCL transport: fold this rank's block partials of slots [first, first+cnt) into the send buffer (one
-// workgroup per slot)
-static __global__ void __launch_bounds__(BLOCK)
+// wave per slot)
+static __global__ void __launch_bounds__(64)
 k_pack(const double* parts, SlotCounts counts, int first, int cnt, unsigned maxmask, double* send, int rank,
        unsigned keepmask) {
-    __shared__ double sh[WAVES];
     const int i = blockIdx.x;
-    double t = fold_src(ScalarSrc{parts + (size_t)(first + i) * PSTRIDE, counts.get(i), 1}, (maxmask >> i) & 1u, sh);
+    double t = fold_wave(parts + (size_t)(first + i) * PSTRIDE, counts.get(i), (maxmask >> i) & 1u);
     if (rank != 0 && !((keepmask >> i) & 1u)) t = 0.0;
     if (threadIdx.x == 0) send[first + i] = t;
 }

@@ -834,7 +834,7 @@ template <class T> class Solver final : public SolverBase {
             a.mbox_local = (P2PWords*)ctx->mbox_local;
             for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
             a.timeout = ptimeout_dev_; a.keepmask = keepmask;
-            launch_b(C_GATHER, k_exchange, cnt, BLOCK, a);
+            launch_b(C_GATHER, k_exchange, cnt, 64, a);
             for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
             return;
         }
@@ -842,7 +842,7 @@ template <class T> class Solver final : public SolverBase {
         SlotCounts counts;
         std::memset(&counts, 0, sizeof(counts));
         for (int i = 0; i < cnt; ++i) counts.set(i, slot_n[first + i]);
-        launch_b(C_GATHER, k_pack, cnt, BLOCK, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p, ctx->rank,
+        launch_b(C_GATHER, k_pack, cnt, 64, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p, ctx->rank,
                  keepmask);
         BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
                               ctx->comm, ctx->stream));

@@ -1322,11 +1322,14 @@ template <class T> class Solver final : public SolverBase {
         M = o.lbfgs_memory;
         alloc_history();
         lbfgs_reset_all();
-        if (o.lbfgs_compact && M > CM) throw Error(BZ_ERR_ARG, "lbfgs_compact supports lbfgs_memory <= 5");
-        compact_ok = o.lbfgs_compact && M >= 1;
+        if (o.lbfgs_compact < 0 || o.lbfgs_compact > 2) throw Error(BZ_ERR_ARG, "lbfgs_compact must be 0, 1 or 2 (auto)");
+        if (o.lbfgs_compact == 1 && M > CM) throw Error(BZ_ERR_ARG, "lbfgs_compact supports lbfgs_memory <= 5");
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
         fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack && desc.D_kind <= BZ_D_BOX &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
+        // auto: the compact representation where it makes the whole iteration one pass (the fused separable
+        // path, memory within its capacity), the two-loop recursion everywhere else
+        compact_ok = M >= 1 && (o.lbfgs_compact == 1 || (o.lbfgs_compact == 2 && fused_ok && M <= CM));
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
             // block per CU) and the vector must be long enough for 2m-1 grid barriers to beat 2m launches

@@ -26,9 +26,12 @@ class LBFGS:
     """ProximalAlgorithms.LBFGS(memory) — the only `directions` the shipped scripts select
     (demo/rosenbrock.jl:103,275)."""
 
-    def __init__(self, memory=5, compact=False):
+    def __init__(self, memory=5, compact=None):
         self.memory = int(memory)
-        self.compact = bool(compact)      # same operator, compact (one-reduction-phase) evaluation
+        # how the operator is evaluated (bz_panoc_opts.lbfgs_compact): False = two-loop recursion in the
+        # reference's operation order; True = compact representation (same operator, one pass per iteration
+        # on the separable path); None = compact where that one-pass kernel applies, two-loop elsewhere
+        self.compact = None if compact is None else bool(compact)
 
 
 class NoAcceleration:
@@ -159,7 +162,8 @@ class PANOCplus:
         o.minimum_gamma, o.alpha, o.beta = float(self.minimum_gamma), float(self.alpha), float(self.beta)
         o.max_backtracks, o.lbfgs_memory, o.fuse = int(self.max_backtracks), self.directions.memory, int(bool(self.fuse))
         o.persist = int(bool(self.persist))
-        o.lbfgs_compact = int(bool(getattr(self.directions, "compact", False)))
+        cm = getattr(self.directions, "compact", None)
+        o.lbfgs_compact = 2 if cm is None else int(bool(cm))
         return o
 
     def __call__(self, *, f, g, x0):

@@ -5,7 +5,7 @@
  * C++ bench binary".
  *
  *   cc -O2 -Iinclude examples/panoc_capi.c -Lbazinga.jl_amd -lbazinga_hip -Wl,-rpath,$PWD/bazinga.jl_amd -lm -o panoc_capi
- *   ./panoc_capi [n] [steps] [compact]
+ *   ./panoc_capi [n] [steps] [lbfgs_compact: 0 two-loop | 1 compact | 2 auto (default)]
  */
 #include <math.h>
 #include <stdint.h>
@@ -44,7 +44,7 @@ static double now_s(void) {
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? (int64_t)atof(argv[1]) : 1000000;
     const int64_t steps = argc > 2 ? atoll(argv[2]) : 200;
-    const int compact = argc > 3 ? atoi(argv[3]) : 1;
+    const int compact = argc > 3 ? atoi(argv[3]) : 2;      /* bz_panoc_opts.lbfgs_compact: 0 two-loop, 1 compact, 2 auto */
     double *q = malloc(n * sizeof(double)), *b = malloc(n * sizeof(double)), *mu = malloc(n * sizeof(double));
     double *y = calloc(n, sizeof(double)), *x0 = calloc(n, sizeof(double)), *x = malloc(n * sizeof(double));
     double *s = malloc(n * sizeof(double)), *yo = malloc(n * sizeof(double)), *muo = malloc(n * sizeof(double));
@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
     double sc[16];
     CHECK(bz_panoc_scalars(p, sc));
     printf("panoc: n=%lld %s L-BFGS  %.1f iterations/s  (%.1f us/iteration)  k=%.0f gamma=%.6g stop_norm=%.3e\n",
-           (long long)n, compact ? "compact" : "two-loop", (double)steps / (t1 - t0), 1e6 * (t1 - t0) / (double)steps,
+           (long long)n, compact == 0 ? "two-loop" : compact == 1 ? "compact" : "default (auto)", (double)steps / (t1 - t0), 1e6 * (t1 - t0) / (double)steps,
            sc[0], sc[1], sc[7]);
     bz_problem_destroy(p);
     bz_ctx_destroy(ctx);

@@ -178,15 +178,16 @@ typedef struct {
                                 register-resident when the vector fits (<= 48 packs/thread)
                                 and is long enough; 0: one kernel per two-loop step.
                                 Same arithmetic, different (fixed) summation tree.       */
-    int32_t lbfgs_compact;   /* 1: evaluate the SAME L-BFGS operator in its compact
-                                (Byrd-Nocedal-Schnabel) representation (M <= 5): no
-                                sequential reductions, so for c = Identity with an
-                                element-wise f the whole iteration is ONE streaming pass
-                                over 2M+11 vectors and one reduction phase (one cross-GPU
-                                exchange) instead of 2M+1.  An alternate rounding of the
-                                two-loop recursion (its iterates track the fp64 oracle as
-                                closely as the two-loop kernels' do); default 0 = the
-                                reference's operation order.                             */
+    int32_t lbfgs_compact;   /* how the L-BFGS operator (ProximalAlgorithms.LBFGS) is evaluated:
+                                0: two-loop recursion, the reference's operation order (2M sequentially
+                                   dependent reductions per application);
+                                1: compact (Byrd-Nocedal-Schnabel) representation (M <= 5): no sequential
+                                   reductions, so for c = Identity with an element-wise f the whole
+                                   iteration is ONE streaming pass over 2M+11 vectors and one reduction
+                                   phase (one cross-GPU exchange) instead of 2M+1.  The same operator, an
+                                   alternate rounding: its iterates track the fp64 oracle as closely as the
+                                   two-loop kernels' do;
+                                2 (default): 1 where that one-pass kernel applies, 0 elsewhere.         */
     int32_t reserved;
 } bz_panoc_opts;
 

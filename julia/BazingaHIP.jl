@@ -35,7 +35,7 @@ Base.@kwdef mutable struct PanocOpts
     tol::Float64 = 1e-8; maxit::Int64 = 1000; freq::Int32 = 10; verbose::Int32 = 0
     minimum_gamma::Float64 = 1e-7; alpha::Float64 = 0.95; beta::Float64 = 0.5
     max_backtracks::Int32 = 20; lbfgs_memory::Int32 = 5; fuse::Int32 = 1; persist::Int32 = 1
-    lbfgs_compact::Int32 = 0; reserved::Int32 = 0
+    lbfgs_compact::Int32 = 2; reserved::Int32 = 0
 end
 Base.@kwdef mutable struct PanocStats
     iters::Int64 = 0; f_z::Float64 = 0; g_z::Float64 = 0; al_z::Float64 = 0; gamma::Float64 = 0
@@ -86,10 +86,10 @@ end
 Bazinga.eval!(cx, c::DenseAffine, x) = (cx .= c.A * x .- c.b; nothing)
 Bazinga.jtprod!(jtv, c::DenseAffine, x, v) = (jtv .= c.A' * v; nothing)
 
-"`LBFGS(M; compact = false)`: compact = true evaluates the same operator in its compact representation (bz_panoc_opts.lbfgs_compact)"
+"`LBFGS(M; compact = nothing)`: how the operator is evaluated (bz_panoc_opts.lbfgs_compact) — `false` the two-loop recursion in the reference's order, `true` the compact representation, `nothing` (default) compact where the one-pass kernel applies"
 struct LBFGS
-    memory::Int; compact::Bool
-    LBFGS(memory = 5; compact = false) = new(memory, compact)
+    memory::Int; compact::Union{Nothing,Bool}
+    LBFGS(memory = 5; compact = nothing) = new(memory, compact)
 end
 
 # ---- lowering: pattern-match the oracle structs -> bz_problem_desc ----------------------------
@@ -172,7 +172,7 @@ as ProximalAlgorithms.PANOCplus as the reference configures it (demo/rosenbrock.
 function PANOCplus(; directions = nothing, maxit = 1000, tol = 1e-8, verbose = false, freq = 10,
                    minimum_gamma = 1e-7, alpha = 0.95, beta = 0.5, max_backtracks = 20, kwargs...)
     M = directions === nothing ? 5 : directions.memory
-    compact = directions isa LBFGS && directions.compact
+    compact = !(directions isa LBFGS) || directions.compact === nothing ? 2 : Int(directions.compact)
     PANOCplusHIP(PanocOpts(tol = tol, maxit = min(maxit, typemax(Int64)), freq = min(freq, typemax(Int32)),
                            verbose = verbose, minimum_gamma = minimum_gamma, alpha = alpha, beta = beta,
                            max_backtracks = max_backtracks, lbfgs_memory = M, lbfgs_compact = compact))

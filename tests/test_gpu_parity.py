@@ -131,13 +131,13 @@ def _err(a, b):
 
 
 def run_traces(bz, ref, dev, orc, n, mu, y, x0, iters, fuse=True, minimum_gamma=1e-7, dtype=np.float64,
-               ny=None):
+               ny=None, compact=None):
     """Step the device solver and the oracle side by side.  Returns rows
     (k, err_x, err_z, gamma_dev, gamma_ref, stop_dev, stop_ref, fused, self_sensitivity)."""
     ny = n if ny is None else ny
     prob = bz.Problem(*dev, n, ny, dtype)
     prob.set_multipliers(mu, y)
-    sub = bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=minimum_gamma, fuse=fuse)
+    sub = bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=minimum_gamma, fuse=fuse, directions=bz.LBFGS(5, compact=compact))
     prob.panoc_begin(sub.c_opts(), x0)
     its, sts = [], []
     for red in (None, LongDoubleReducer()):
@@ -173,15 +173,18 @@ def iter_tol(self_sens):
 
 @pytest.mark.parametrize("n", [1000, 4097, 200003])
 @pytest.mark.parametrize("D", ["box", "free"])
-def test_panoc_iterates_match_oracle(bz, ref, n, D):
+@pytest.mark.parametrize("form", ["default", "two-loop"])
+def test_panoc_iterates_match_oracle(bz, ref, n, D, form):
     """Per-iteration parity of x and z over the first 30 PANOCplus iterations
-    (two different multiplier settings: y = 0 as in outer iteration 1, and y != 0)."""
+    (two different multiplier settings: y = 0 as in outer iteration 1, and y != 0) against the oracle in the
+    reference's two-loop form — for the library default (the compact representation on this separable path)
+    and for the two-loop kernels."""
     d, dev, orc = make_cfg2(bz, ref, n, D=D)
     rng = np.random.default_rng(3)
     for y in (np.zeros(n), rng.standard_normal(n)):
         mu = np.full(n, 0.1)
         x0 = np.zeros(n)
-        prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 30)
+        prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 30, compact=None if form == "default" else False)
         for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
             assert abs(g_d - g_r) <= 1e-13 * g_r, f"gamma differs at k={k}"
             assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k}: {ex} {ez}"
@@ -204,7 +207,8 @@ def test_fused_equals_generic_bitwise(bz, ref, g):
     for fuse in (True, False):
         prob = bz.Problem(*dev, n, n, np.float64)
         prob.set_multipliers(mu, y)
-        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse).c_opts(), x0)
+        # (the two-loop form: with the compact one p, w are summed by different kernels in the two runs)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse, directions=bz.LBFGS(5, compact=False)).c_opts(), x0)
         for _ in range(25):
             prob.panoc_step()
         out.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"),
@@ -518,7 +522,7 @@ def test_persistent_two_loop_matches_kernel_chain(bz, ref):
     for persist in (True, False):
         prob = bz.Problem(*dev, n, n, np.float64)
         prob.set_multipliers(mu, y)
-        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist).c_opts(), np.zeros(n))
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist, directions=bz.LBFGS(5, compact=False)).c_opts(), np.zeros(n))
         for _ in range(14):
             prob.panoc_step()
         out.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(), prob.profile()))
@@ -542,7 +546,7 @@ def test_persistent_kernel_is_used_at_benchmark_size(bz, ref):
     prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
                       bz.ClosedSet(bz.IndBox(-1.0, 1.0)), n, n, np.float64)
     prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
-    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, directions=bz.LBFGS(5, compact=False)).c_opts(), np.zeros(n))
     prob.profile_enable(True)
     for _ in range(8):
         prob.panoc_step()
@@ -642,7 +646,7 @@ def test_headline_size_iterates_match_oracle(bz, ref):
     n = 10_000_000
     d, dev, orc = make_cfg2(bz, ref, n)
     prob, st, rows = run_traces(bz, ref, dev, orc, n, np.full(n, 0.1), np.zeros(n), np.zeros(n), 7,
-                                minimum_gamma=float(np.finfo(float).eps))
+                                minimum_gamma=float(np.finfo(float).eps), compact=False)
     for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
         assert abs(g_d - g_r) <= 1e-13 * g_r
         assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k}: {ex} {ez}"

@@ -356,7 +356,7 @@ def main():
     # 2M + 11 vectors and one reduction phase (one cross-GPU exchange at N > 1), against 2M sequential
     # reductions for the two-loop recursion.  Same operator, alternate rounding — its iterates stay as close
     # to the fp64 oracle's as the two-loop kernels' do (oracle: LBFGSCompactOperator; tests:
-    # test_compact_lbfgs_*; tools/err_compact_vs_twoloop.py) — and it is what LBFGS(M) means by default on this
+    # test_compact_lbfgs_*; tests/stress/err_compact_vs_twoloop.py) — and it is what LBFGS(M) means by default on this
     # path (lbfgs_compact = 2, "auto").  --two-loop times the reference's order.
     compact = not args.two_loop
     popts = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),

@@ -1,6 +1,6 @@
 """Random-shape sweep of the kernel-level parity tests (stencil / dense AL gradient, pairwise sets)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import bazinga_jl_amd as bz

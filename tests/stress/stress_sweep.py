@@ -1,7 +1,7 @@
 """Runs the randomised ALPS parity case of tests/test_gpu_parity.py over many more seeds than the suite does
 (development aid: hunts for rare branch combinations — backtracks, gamma halvings, skipped pairs, resets)."""
 import os, sys, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import bazinga_jl_amd as bz

@@ -1,6 +1,6 @@
 """Development aid: print device-vs-oracle iterate errors per PANOCplus state."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bazinga_jl_amd as bz
 from oracle import bazinga_ref as ref

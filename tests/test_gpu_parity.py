@@ -772,7 +772,7 @@ def test_randomised_kinds_alps_parity(bz, ref, seed, form):
     assert a[5] == o[5], tag
     assert a[2] == o[2] or o2[2] != o[2], tag
     # The inner count adds up the lengths of six-odd subsolves, each stopped where a noisy, non-monotone
-    # stop-norm sequence first dips under the inner tolerance: over 576 seeded cases (tools/stress_sweep.py)
+    # stop-norm sequence first dips under the inner tolerance: over 576 seeded cases (tests/stress/stress_sweep.py)
     # device and oracle differ by up to 26 % there (the oracle's perturbed twin by up to 19 %) while agreeing on x
     # to the oracle's own resolution.
     assert abs(a[3] - o[3]) <= max(3, 0.3 * o[3]), tag

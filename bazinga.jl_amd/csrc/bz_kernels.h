@@ -1997,11 +1997,11 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         }
         if constexpr (O32) {
-            sto<T, NT>(x_d, bo, pxd); sto<T, NT>(z, bo, pz); sto<T, NT>(res, bo, pr);
+            sto<T, NT>(x_d, bo, pxd); if (z) sto<T, NT>(z, bo, pz); sto<T, NT>(res, bo, pr);
             sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy);
         } else {
             stp<T, NT>(x_d, i0, cnt, pxd);
-            stp<T, NT>(z, i0, cnt, pz);
+            if (z) stp<T, NT>(z, i0, cnt, pz);
             stp<T, NT>(res, i0, cnt, pr);
             stp<T, NT>(s_new, i0, cnt, pss);
             stp<T, NT>(y_new, i0, cnt, pyy);

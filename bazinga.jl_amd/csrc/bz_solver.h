@@ -99,7 +99,8 @@ enum Slot : int {
     SL_OUTER = 66,     // 2 slots: outer loop
     SL_SCRATCH = 68,   // sink for partials nobody reads
     SL_GP = 69,        // compact L-BFGS: p = S'v, w = Y'v from their own pass, 2*CM slots
-    SL_COUNT = 79
+    SL_ZS = 79,        // 3 slots: sink of the forward-backward step that re-materialises z
+    SL_COUNT = 82
 };
 constexpr int MAX_MEM = 16;
 constexpr int CM = 5;            // capacity of the compact L-BFGS form (pairs)

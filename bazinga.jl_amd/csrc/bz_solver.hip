@@ -298,7 +298,7 @@ template <class T> class Solver final : public SolverBase {
 
     void finish(void* x_out, bz_panoc_stats* st) override {
         require_active();
-        if (x_out) copy_out(x_out, Z_[zc].p, n);
+        if (x_out) { ensure_z(); copy_out(x_out, Z_[zc].p, n); }
         if (st) fill_stats(st);
     }
 
@@ -315,12 +315,13 @@ template <class T> class Solver final : public SolverBase {
         require_active();
         switch (which) {
         case 0: copy_out(out, X_[xc].p, n); break;
-        case 1: copy_out(out, Z_[zc].p, n); break;
+        case 1: ensure_z(); copy_out(out, Z_[zc].p, n); break;
         case 2: copy_out(out, RES_[rc].p, n); break;
         case 3:
             if (!gx_valid) { algrad(X_[xc].p, GX_.p, SL_AUX); gx_valid = true; }
             copy_out(out, GX_.p, n); break;
         case 4:
+            ensure_z();
             if (!gz_valid) { algrad(Z_[zc].p, GZ_.p, SL_AUX); gz_valid = true; }
             copy_out(out, GZ_.p, n); break;
         default: throw Error(BZ_ERR_ARG, "unknown vector id");
@@ -435,6 +436,7 @@ template <class T> class Solver final : public SolverBase {
             begin_dev(po2, x);                                       // alps.jl:66
             run_to_completion();
             const int64_t sub_it = k_;
+            ensure_z();
             x = Z_[zc].p;                                            // x .= sub_sol
             objx = fraw_last + g_z;                                  // alps.jl:68
             tot_inner += sub_it;
@@ -587,6 +589,11 @@ template <class T> class Solver final : public SolverBase {
     // solver state (host scalars)
     bz_panoc_opts opt{};
     bool active = false, fused_ok = false, gx_valid = false, gz_valid = false;
+    // The one-pass compact kernel computes z in registers and does not store it: nothing in a plain iteration
+    // reads it back (the next iterate is x_d, the stopping test uses grad L(z) formed in the same pass), and
+    // the store is the dearest of the kernel's streams (-8 % of its time).  Who does need it — a tau backtrack
+    // (z_curr), the caller asking for the solution — gets it re-materialised bit for bit from x and gamma.
+    bool z_valid = true;
     int xc = 0, rc = 0, zc = 0;
     T alpha = T(0.95), beta = T(0.5), min_gamma = T(1e-7), musqy = T(0);
     T gamma = T(0), tau = T(0), f_x = T(0), g_z = T(0), dot_gr = T(0), ss_res = T(0);
@@ -818,6 +825,15 @@ template <class T> class Solver final : public SolverBase {
     unsigned long long hseq_ = 0;
 
     // multi-GPU: fold this rank's block partials of slots [first, first+cnt) and all-gather
+    // z of the CURRENT state into Z_[zc] if the last fused pass skipped its store:
+    //   z = prox_{gamma g}(x - gamma grad L(x))   — the arithmetic of k_algrad_elem + k_fbstep, which the fused
+    //   passes reproduce bit for bit (test_fused_equals_generic_bitwise)
+    void ensure_z() {
+        if (z_valid) return;
+        algrad(X_[xc].p, D_.p, SL_AUX);                  // scratch gradient: GX_/GZ_ keep their meaning
+        fbstep(X_[xc].p, D_.p, gamma, Z_[zc].p, nullptr, SL_ZS);
+        z_valid = true;
+    }
     // ymask (row-sharded dense c only, where x-space quantities are computed in full by every rank): the
     // slots that are sums over THIS rank's constraint rows and must be added up; the others count once
     void gather(int first, int cnt, unsigned maxmask, unsigned ymask = 0u) {
@@ -1343,7 +1359,7 @@ template <class T> class Solver final : public SolverBase {
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;
         last_nbt = 0; last_fused = false; tau = T(0); last_ys = T(0); fbe_last = T(0);
-        xc = 0; rc = 0; zc = 0;
+        xc = 0; rc = 0; zc = 0; z_valid = true;
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
         const T eps = std::numeric_limits<T>::epsilon();
@@ -1435,7 +1451,7 @@ template <class T> class Solver final : public SolverBase {
         constexpr int NFC = 10 + 4 * CM + 2;                          // slots of k_fused_compact
         static_assert(SL_TRIAL + NFC <= SL_AUX, "k_fused_compact's slots overlap the next group");
         const int m_at_trial = (int)order.size();
-        bool tail_used = false;
+        bool tail_used = false, z_skipped = false;
         unsigned long long tail_ticket = 0;
         bool gram_from_trial = false;
         tau = T(1);
@@ -1460,12 +1476,15 @@ template <class T> class Solver final : public SolverBase {
                               desc.D_kind == BZ_D_BOX && !P.D_lo_vec && !P.D_hi_vec && CV.m == CM;
 #define BZ_LAUNCH_FC(NT_, SPEC_)                                                                                  \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, SPEC_>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
-           gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
+           gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
+            static const int skipz_env = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
+            T* const zstore = skipz_env ? (T*)nullptr : Z_[zn].p;
+            z_skipped = zstore == nullptr;
             static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
             const bool off32 = off32_env && spec && (double)vcap * sizeof(T) < 4.0e9;
 #define BZ_LAUNCH_FC3(NT_)                                                                                        \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, true, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
-           gamma, X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
+           gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
             if (off32 && nt) BZ_LAUNCH_FC3(true);
             else if (off32) BZ_LAUNCH_FC3(false);
             else if (nt && spec) BZ_LAUNCH_FC(true, true);
@@ -1554,7 +1573,12 @@ template <class T> class Solver final : public SolverBase {
             const T nr = std::sqrt(ss_res);
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));
-            if (f_z > f_z_upp + tol && gamma >= min_gamma) {
+            const bool halve = f_z > f_z_upp + tol && gamma >= min_gamma;
+            const T FBE_new = f_z_upp + g_z;
+            // not a plain iteration: z of the state this step started from may be needed (z_curr below), and
+            // it must be formed with the gamma of that state
+            if (!z_valid && (halve || !(FBE_new <= threshold || k >= max_bt))) ensure_z();
+            if (halve) {
                 gamma = gamma * T(0.5); ++n_halv;
                 if (gamma < min_gamma)
                     std::fprintf(stderr, "Warning: stepsize `gamma` became too small (%g)\n", (double)gamma);
@@ -1563,7 +1587,6 @@ template <class T> class Solver final : public SolverBase {
                 fused_this = false;
                 continue;
             }
-            const T FBE_new = f_z_upp + g_z;
             if (FBE_new <= threshold || k >= max_bt) break;
             tau = (k >= max_bt - 1) ? T(0) : tau / T(2);
             ++nbt; ++n_bt;
@@ -1601,6 +1624,7 @@ template <class T> class Solver final : public SolverBase {
         }
         stop_norm_ = v[9];
         xc = xcur; rc = rn; zc = zn;
+        z_valid = !(z_skipped && fused_this);      // the generic trial writes z; an accepted fused one may not have
         last_nbt = nbt; last_fused = fused_this;
         if (fused_this) ++n_fused;
     }

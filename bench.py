@@ -506,7 +506,7 @@ def main():
     if world == 1 and not args.no_extras:
         if compact:
             popts_tl = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),
-                                    fuse=not args.no_fuse, directions=bz.LBFGS(M_LBFGS)).c_opts()
+                                    fuse=not args.no_fuse, directions=bz.LBFGS(M_LBFGS, compact=False)).c_opts()
             p2 = make_problem(ctx, popts_tl)
             r2 = timed_run(p2, args.steps, args.warmup)
             p2.close()
@@ -538,8 +538,9 @@ def main():
         #   k_axpy_dot        : 3R+1W per step, the middle step 2R+1W -> (8m-5)/(2m-1) passes on average
         #   k_fused_sep       : last axpy + x_d (4) + 2 AL gradients (2*6) + FB step (4) + update/stop (8)
         #   k_fused_compact   : the WHOLE iteration is this one launch: (8m+1) + 12 + 4 + 8 = 65 passes at m = 5
-        #                       (it moves 2m + 11 = 21: reads res, S[m], Y[m], x, q, b, mu, mu*y; writes x_d, z,
-        #                       res, s, y; the next application's S'res, Y'res come out of the same pass)
+        #                       (it moves 2m + 10 = 20: reads res, S[m], Y[m], x, q, b, mu, mu*y; writes x_d, res, s, y —
+        #                       z stays in registers and is re-materialised on demand; the next application's
+        #                       S'res, Y'res come out of the same pass)
         alg_passes = {"k_twoloop_persist": (8 * m + 1) - 4,
                       "k_axpy_dot": (4.0 * (2 * m - 2) + 3.0) / (2 * m - 1) if m >= 1 else 0.0,
                       "k_fused_sep": 4 + 12 + 4 + 8, "k_dot": 2}

@@ -1883,6 +1883,32 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
     block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
 }
 
+// history as iterates -> history as pairs: S[i] = XH[i+1] - XH[i], Y[i] = RH[i+1] - RH[i] for the MM stored pairs
+// (run when an iteration leaves the plain path and the classic kernels need the difference vectors)
+template <class T, int MM> struct SnapVecs {
+    const T* XH[MM + 1];
+    const T* RH[MM + 1];
+    T* S[MM];
+    T* Y[MM];
+};
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK) k_pairs_from_snapshots(SnapVecs<T, MM> V, int64_t n) {
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        Pack<T> xh[MM + 1], rh[MM + 1];
+#pragma unroll
+        for (int i = 0; i <= MM; ++i) { xh[i] = ld(V.XH[i], i0, cnt); rh[i] = ld(V.RH[i], i0, cnt); }
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {
+            Pack<T> s, y;
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) { s.v[e] = xh[i + 1].v[e] - xh[i].v[e]; y.v[e] = rh[i + 1].v[e] - rh[i].v[e]; }
+            st(V.S[i], i0, cnt, s);
+            st(V.Y[i], i0, cnt, y);
+        }
+    });
+}
+
 // The separable fast path with the compact direction: ONE pass computes d from (res, S, Y), then x_d, both AL
 // gradients, the FB step, the new pair, its Gram products with the stored pairs and the stop norm.
 //   reads : res, S[m], Y[m], x, q, b, mu, mu*y   writes: x_d, z, res, s_new, y_new
@@ -1890,7 +1916,7 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
 //           + 10 + 2MM + i: <s_i, -res> ; + 10 + 3MM + i: <y_i, -res> ; then <s_new, -res>, <y_new, -res>
 //           with res the NEW residual: the p and w of the next application, whichever pairs it keeps —
 //           so the whole iteration is this one pass (S and Y are in registers here anyway)
-template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false>
+template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, bool XR = false>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
@@ -1948,6 +1974,20 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             for (int i = 0; i < MM; ++i)
                 if (i < m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
         }
+        if constexpr (XR) {
+            // history kept as ITERATES: V.S[i], V.Y[i] are the snapshots x_{k-MM+i}, res_{k-MM+i} (x and res_prev the
+            // newest), and the pairs are their successive differences — the very subtractions that produced the
+            // stored s and y (s = x_d - x, y = res - res_prev), so the same bits, for two write streams less
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+#pragma unroll
+                for (int e = 0; e < PackN<T>::N; ++e) {
+                    const T nx = (i + 1 < MM) ? ps[i + 1].v[e] : px.v[e];
+                    const T nr = (i + 1 < MM) ? py[i + 1].v[e] : prp.v[e];
+                    ps[i].v[e] = nx - ps[i].v[e];
+                    py[i].v[e] = nr - py[i].v[e];
+                }
+        }
         compact_d<T, MM>(m, H0, u1, u2h, prp, ps, py, d);
         Pack<T> pxd, pz, pr, pss, pyy;
 #pragma unroll
@@ -1998,13 +2038,15 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         }
         if constexpr (O32) {
             sto<T, NT>(x_d, bo, pxd); if (z) sto<T, NT>(z, bo, pz); sto<T, NT>(res, bo, pr);
-            sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy);
+            if constexpr (!XR) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }
         } else {
             stp<T, NT>(x_d, i0, cnt, pxd);
             if (z) stp<T, NT>(z, i0, cnt, pz);
             stp<T, NT>(res, i0, cnt, pr);
-            stp<T, NT>(s_new, i0, cnt, pss);
-            stp<T, NT>(y_new, i0, cnt, pyy);
+            if constexpr (!XR) {
+                stp<T, NT>(s_new, i0, cnt, pss);
+                stp<T, NT>(y_new, i0, cnt, pyy);
+            }
         }
     });
     block_reduce_store<NS>(acc, 1u << 9, parts, slot0);

@@ -560,7 +560,10 @@ template <class T> class Solver final : public SolverBase {
     int grid = 1, grid_y = 1;
     ElemParams<T> P;
     DBuf<T> q_, b_, gu_, glo_, ghi_, dlo_, dhi_, mu_, muy_, ymul_, sproj_;
-    DBuf<T> X_[3], RES_[2], Z_[2], GX_, GZ_, D_, TMP_;
+    // x and res live in rings long enough to keep the last CM+1 iterates alive (history as iterates, see
+    // xr_run_): CM+1 snapshots + the slot being written (+ one more x slot for the tau blend)
+    static constexpr int NXR = CM + 3, NRR = CM + 2;
+    DBuf<T> X_[NXR], RES_[NRR], Z_[2], GX_, GZ_, D_, TMP_;
     DBuf<T> A_, cb_, CX_, YU_, GT_;          // DenseAffine c: A[ny][n], b, c(x), yupd, A'v row-chunk partials
     int rows_per_chunk = 1, nrowchunks = 1;
     DBuf<T> FA_, fb_, FR_, DFX_;             // dense f: matrix, vector, residual / Qx, gradient of f
@@ -594,6 +597,27 @@ template <class T> class Solver final : public SolverBase {
     // the store is the dearest of the kernel's streams (-8 % of its time).  Who does need it — a tau backtrack
     // (z_curr), the caller asking for the solution — gets it re-materialised bit for bit from x and gamma.
     bool z_valid = true;
+    // History as iterates: once the last CM iterations were plain ones that each inserted their pair, the CM
+    // stored pairs are the successive differences of the last CM+1 iterates, which the long x / res rings
+    // still hold — the fused pass then reads those snapshots instead of S and Y (same number of streams,
+    // same bits: s = x_d - x, y = res - res_prev are re-formed by the very subtraction that made them) and
+    // stops WRITING s and y (two of its dearest streams).  The first iteration that is not a plain one
+    // turns the snapshots back into pairs (k_pairs_from_snapshots) and the classic kernels take over.
+    int xr_run_ = 0;             // consecutive plain, pair-inserting iterations so far
+    int xr_env_ = 1, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
+    bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
+    void materialize_pairs() {
+        if (!sy_stale_) return;
+        SnapVecs<T, CM> V;
+        std::memset(&V, 0, sizeof(V));
+        for (int i = 0; i <= CM; ++i) {
+            V.XH[i] = X_[(xc - CM + i + NXR) % NXR].p;
+            V.RH[i] = RES_[(rc - CM + i + NRR) % NRR].p;
+        }
+        for (int i = 0; i < CM; ++i) { V.S[i] = S_[order[CM - 1 - i]].p; V.Y[i] = Y_[order[CM - 1 - i]].p; }
+        launch(C_MISC, k_pairs_from_snapshots<T, CM>, grid, V, n);
+        sy_stale_ = false;
+    }
     int xc = 0, rc = 0, zc = 0;
     T alpha = T(0.95), beta = T(0.5), min_gamma = T(1e-7), musqy = T(0);
     T gamma = T(0), tau = T(0), f_x = T(0), g_z = T(0), dot_gr = T(0), ss_res = T(0);
@@ -1359,7 +1383,9 @@ template <class T> class Solver final : public SolverBase {
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;
         last_nbt = 0; last_fused = false; tau = T(0); last_ys = T(0); fbe_last = T(0);
-        xc = 0; rc = 0; zc = 0; z_valid = true;
+        xc = 0; rc = 0; zc = 0; z_valid = true; xr_run_ = 0; sy_stale_ = false;
+        xr_env_ = std::getenv("BZ_XR") ? std::atoi(std::getenv("BZ_XR")) : 1;
+        skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
         const T eps = std::numeric_limits<T>::epsilon();
@@ -1455,8 +1481,8 @@ template <class T> class Solver final : public SolverBase {
         unsigned long long tail_ticket = 0;
         bool gram_from_trial = false;
         tau = T(1);
-        const int xp = xc, xd = (xc + 1) % 3, xb = (xc + 2) % 3;
-        const int rp = rc, rn = 1 - rc, zp = zc, zn = 1 - zc;
+        const int xp = xc, xd = (xc + 1) % NXR, xb = (xc + 2) % NXR;
+        const int rp = rc, rn = (rc + 1) % NRR, zp = zc, zn = 1 - zc;
         int xcur = xd;
         bool have_trial = false, fused_this = false;
         if (fused_ok && use_compact) {
@@ -1477,11 +1503,29 @@ template <class T> class Solver final : public SolverBase {
 #define BZ_LAUNCH_FC(NT_, SPEC_)                                                                                  \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, SPEC_>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
-            static const int skipz_env = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
-            T* const zstore = skipz_env ? (T*)nullptr : Z_[zn].p;
+            T* const zstore = skipz_env_ ? (T*)nullptr : Z_[zn].p;
             z_skipped = zstore == nullptr;
             static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
             const bool off32 = off32_env && spec && (double)vcap * sizeof(T) < 4.0e9;
+            const bool xr = xr_env_ && off32 && xr_run_ >= CM && (int)order.size() == CM;
+            if (sy_stale_ && !xr) materialize_pairs();
+            if (xr) {
+                CompactVecs<T, CM> XV;
+                XV.m = CM;
+                for (int i = 0; i < CM; ++i) {
+                    XV.S[i] = X_[(xc - CM + i + NXR) % NXR].p;
+                    XV.Y[i] = RES_[(rc - CM + i + NRR) % NRR].p;
+                }
+                if (nt)
+                    launch(C_FUSED, k_fused_compact<T, CM, true, true, true, true>, gfc, XV, CC, (const T*)X_[xp].p,
+                           (const T*)RES_[rp].p, P, gamma, X_[xd].p, zstore, RES_[rn].p, (T*)nullptr, (T*)nullptr, n, parts_.p,
+                           (int)SL_TRIAL);
+                else
+                    launch(C_FUSED, k_fused_compact<T, CM, false, true, true, true>, gfc, XV, CC, (const T*)X_[xp].p,
+                           (const T*)RES_[rp].p, P, gamma, X_[xd].p, zstore, RES_[rn].p, (T*)nullptr, (T*)nullptr, n, parts_.p,
+                           (int)SL_TRIAL);
+                sy_stale_ = true;
+            } else
 #define BZ_LAUNCH_FC3(NT_)                                                                                        \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, true, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
@@ -1578,6 +1622,8 @@ template <class T> class Solver final : public SolverBase {
             // not a plain iteration: z of the state this step started from may be needed (z_curr below), and
             // it must be formed with the gamma of that state
             if (!z_valid && (halve || !(FBE_new <= threshold || k >= max_bt))) ensure_z();
+            // ... and the classic kernels that finish this iteration need the stored pairs as vectors
+            if (sy_stale_ && (halve || !(FBE_new <= threshold || k >= max_bt))) materialize_pairs();
             if (halve) {
                 gamma = gamma * T(0.5); ++n_halv;
                 if (gamma < min_gamma)
@@ -1621,7 +1667,10 @@ template <class T> class Solver final : public SolverBase {
             lbfgs_insert(ys, yty, gsy, gyy);
         } else {
             ++n_skips;
+            materialize_pairs();         // (history as iterates: the window stops being contiguous here)
         }
+        // history as iterates is possible after CM plain iterations in a row that each inserted their pair
+        xr_run_ = (fused_this && use_compact && ys > T(0) && xcur == xd) ? xr_run_ + 1 : 0;
         stop_norm_ = v[9];
         xc = xcur; rc = rn; zc = zn;
         z_valid = !(z_skipped && fused_this);      // the generic trial writes z; an accepted fused one may not have

@@ -5,6 +5,8 @@ iterates of the full solve agree within the north-star tolerance 1e-10 relative.
 
 Oracle provenance and its "parity unpinned" status at iterate level: oracle/bazinga_ref.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1030,3 +1032,50 @@ def test_config5_size_closed_form(bz, ref):
                     np.maximum(np.abs(r) - d["lam"], 0)))
     assert np.max(viol) <= 1e-4
     assert not np.any(x0)
+
+
+@pytest.mark.parametrize("n,iters,start", [(30011, 160, "random"), (400003, 60, "random"), (200003, 470, "zero")])
+def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, start):
+    """Two storage tricks of the one-pass compact kernel change WHAT is written, never a value:
+    (1) once the last five iterations were plain ones, the stored pairs are re-formed from the last six iterates
+        kept in the x / res rings (s = x_d - x, y = res - res_prev: the same subtractions) and s, y are no longer
+        written; the first iteration that is not plain turns the snapshots back into pairs;
+    (2) z is not stored and is re-materialised on demand.
+    With both off, both on, and each alone, runs that go through gamma halvings, tau backtracks, and — the
+    "zero" start run to convergence — skipped pairs and re-entries must produce identical bits."""
+    d, dev, orc = make_cfg2(bz, ref, n)
+    rng = np.random.default_rng(9)
+    mu = np.full(n, 0.1)
+    y = rng.standard_normal(n) if start == "random" else np.zeros(n)
+    x0 = rng.standard_normal(n) * 0.05 if start == "random" else np.zeros(n)
+    runs = []
+    try:
+        for xr, skipz in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "1")):
+            os.environ["BZ_XR"], os.environ["BZ_SKIPZ"] = xr, skipz
+            prob = bz.Problem(*dev, n, n, np.float64)
+            prob.set_multipliers(mu, y)
+            prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps)).c_opts(), x0)
+            prob.profile_enable(True)
+            zs = []
+            for k in range(iters):
+                prob.panoc_step()
+                if k % 37 == 5:
+                    zs.append(prob.panoc_vector("z"))            # mid-run read-outs must not disturb anything
+            st = prob.panoc_stats()
+            runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars(), zs,
+                         (st.n_backtracks, st.n_gamma_halvings, st.n_lbfgs_skips, st.n_fused_iters), prob.profile()["misc"]["launches"]))
+            prob.close()
+    finally:
+        os.environ.pop("BZ_XR", None)
+        os.environ.pop("BZ_SKIPZ", None)
+    base = runs[0]
+    for r in runs[1:]:
+        assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]) and np.array_equal(r[2], base[2])
+        assert all(np.array_equal(a, b) for a, b in zip(r[4], base[4]))
+        for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "FBE"):
+            assert r[3][key] == base[3][key], key
+        assert r[5] == base[5]
+    assert base[5][3] >= iters - 12                      # the fused pass served (almost) every iteration
+    if start == "zero":
+        assert base[5][2] > 0                            # pairs were skipped: the snapshots had to become pairs again
+        assert runs[1][6] > runs[0][6]                   # ... by k_pairs_from_snapshots (category misc)

@@ -538,9 +538,11 @@ def main():
         #   k_axpy_dot        : 3R+1W per step, the middle step 2R+1W -> (8m-5)/(2m-1) passes on average
         #   k_fused_sep       : last axpy + x_d (4) + 2 AL gradients (2*6) + FB step (4) + update/stop (8)
         #   k_fused_compact   : the WHOLE iteration is this one launch: (8m+1) + 12 + 4 + 8 = 65 passes at m = 5
-        #                       (it moves 2m + 10 = 20: reads res, S[m], Y[m], x, q, b, mu, mu*y; writes x_d, res, s, y —
-        #                       z stays in registers and is re-materialised on demand; the next application's
-        #                       S'res, Y'res come out of the same pass)
+        #                       (in steady state it moves 2m + 8 = 18: reads res, the m+1 last iterates and the m
+        #                       last residuals the pairs are re-formed from, q, b, mu, mu*y; writes x_d and res —
+        #                       z stays in registers and is re-materialised on demand, s and y are never stored;
+        #                       the next application's S'res, Y'res come out of the same pass.  While the rings
+        #                       fill, or after a rejected step, the stored-pair form moves 2m + 10 = 20)
         alg_passes = {"k_twoloop_persist": (8 * m + 1) - 4,
                       "k_axpy_dot": (4.0 * (2 * m - 2) + 3.0) / (2 * m - 1) if m >= 1 else 0.0,
                       "k_fused_sep": 4 + 12 + 4 + 8, "k_dot": 2}

@@ -183,7 +183,7 @@ typedef struct {
                                    dependent reductions per application);
                                 1: compact (Byrd-Nocedal-Schnabel) representation (M <= 5): no sequential
                                    reductions, so for c = Identity with an element-wise f the whole
-                                   iteration is ONE streaming pass over 2M+10 vectors and one reduction
+                                   iteration is ONE streaming pass over 2M+8..2M+10 vectors and one reduction
                                    phase (one cross-GPU exchange) instead of 2M+1.  The same operator, an
                                    alternate rounding: its iterates track the fp64 oracle as closely as the
                                    two-loop kernels' do;

@@ -61,7 +61,9 @@ def main(tag="r01"):
     if summary:
         with open(os.path.join(out_dir, "pmc_dominant_kernel.json"), "w") as fh:
             json.dump({"n": 10_000_000, "source": f"profiles/{tag}_pmc_hbm_traffic_n1e7.json",
-                       "kernels": {k.replace("bz::", "").split("<")[0]: v["hbm_bytes_per_launch"] for k, v in summary.items()}}, fh, indent=1)
+                       # several instantiations of one kernel: the one that served most launches (the steady state)
+                       "kernels": {k.replace("bz::", "").split("<")[0]: v["hbm_bytes_per_launch"]
+                                   for k, v in sorted(summary.items(), key=lambda kv: kv[1]["launches_fetch_pass"])}}, fh, indent=1)
     # same-run agreement of the two clocks on the dominant kernel: bench.py's dispatch-bound HIP events
     # (its JSON line in prof_stats.log) against rocprofv3's kernel trace over the SAME launches (the timed
     # region = launches [warmup, warmup + steps) of the first problem the bench creates)

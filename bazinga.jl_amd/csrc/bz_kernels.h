@@ -1909,6 +1909,60 @@ __global__ void __launch_bounds__(BLOCK) k_pairs_from_snapshots(SnapVecs<T, MM> 
     });
 }
 
+// fixed-point residual of one element at a stored iterate:  z = prox_{gamma g}(x - gamma grad L(x)), res = x - z —
+// operation for operation what the fused passes (and k_algrad_elem + k_fbstep) do at a trial point, so
+// re-evaluating it at an iterate the rings still hold gives back the bits of the residual computed then
+template <class T>
+__device__ __forceinline__ T resid_elem(int fk, int dk, int gk, T xv, const ElemLoads<T>& L, int e, T gamma, T gl,
+                                        T& zz) {
+    ALOut<T> o = al_elem(fk, dk, xv, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+    T t = gamma * o.grad;
+    T y = xv - t;
+    T gterm;
+    zz = prox_elem(gk, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+    return xv - zz;
+}
+
+// history as iterates, residuals not stored -> history as pairs (headline family: f = DiagQuadratic, g = NormL1,
+// D = Box with scalar bounds): S[i] = XH[i+1] - XH[i], Y[i] = r(XH[i+1]) - r(XH[i]) with r re-evaluated, plus
+// the residual and z of the newest iterate — everything the classic kernels need when an iteration leaves
+// the plain path
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_pairs_from_iterates(SnapVecs<T, MM> V, ElemParams<T> P, T gamma, T* __restrict__ res_cur, T* __restrict__ z_cur,
+                      int64_t n) {
+    const T gl = gamma * P.g_lambda;
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        ElemLoads<T> L;
+        L.q = ld(P.q, i0, cnt); L.b = ld(P.b, i0, cnt); L.mu = ld(P.mu, i0, cnt); L.muy = ld(P.muy, i0, cnt);
+        L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
+        L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
+        Pack<T> xh[MM + 1], rh[MM + 1], pz;
+#pragma unroll
+        for (int i = 0; i <= MM; ++i) {
+            xh[i] = ld(V.XH[i], i0, cnt);
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                T zz;
+                rh[i].v[e] = resid_elem<T>((int)BZ_F_DIAG_QUADRATIC, (int)BZ_D_BOX, (int)BZ_G_NORM_L1, xh[i].v[e], L, e,
+                                           gamma, gl, zz);
+                if (i == MM) pz.v[e] = zz;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {
+            Pack<T> sp, yp;
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) { sp.v[e] = xh[i + 1].v[e] - xh[i].v[e]; yp.v[e] = rh[i + 1].v[e] - rh[i].v[e]; }
+            st(V.S[i], i0, cnt, sp);
+            st(V.Y[i], i0, cnt, yp);
+        }
+        st(res_cur, i0, cnt, rh[MM]);
+        st(z_cur, i0, cnt, pz);
+    });
+}
+
 // The separable fast path with the compact direction: ONE pass computes d from (res, S, Y), then x_d, both AL
 // gradients, the FB step, the new pair, its Gram products with the stored pairs and the stop norm.
 //   reads : res, S[m], Y[m], x, q, b, mu, mu*y   writes: x_d, z, res, s_new, y_new
@@ -1916,7 +1970,11 @@ __global__ void __launch_bounds__(BLOCK) k_pairs_from_snapshots(SnapVecs<T, MM> 
 //           + 10 + 2MM + i: <s_i, -res> ; + 10 + 3MM + i: <y_i, -res> ; then <s_new, -res>, <y_new, -res>
 //           with res the NEW residual: the p and w of the next application, whichever pairs it keeps —
 //           so the whole iteration is this one pass (S and Y are in registers here anyway)
-template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, bool XR = false>
+//   XR = 1: V.S / V.Y are the last MM iterates / residuals before (x, res_prev) and the pairs are re-formed
+//           in registers (s_new, y_new not written)
+//   XR = 2: as 1, and the residuals are not read either but re-evaluated from the iterates (resid_elem):
+//           reads the MM+1 iterates, q, b, mu, mu*y ; writes x_d only (res too if `res` is not null)
+template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, int XR = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
@@ -1957,9 +2015,13 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             L.mu = ldo<T, NT>(P.mu, bo); L.muy = ldo<T, NT>(P.muy, bo);
             L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
             L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
-            px = ldo<T, NT>(x, bo); prp = ldo<T, NT>(res_prev, bo);
+            px = ldo<T, NT>(x, bo);
+            if constexpr (XR != 2) prp = ldo<T, NT>(res_prev, bo);
 #pragma unroll
-            for (int i = 0; i < MM; ++i) { ps[i] = ldo<T, NT>(V.S[i], bo); py[i] = ldo<T, NT>(V.Y[i], bo); }
+            for (int i = 0; i < MM; ++i) {
+                ps[i] = ldo<T, NT>(V.S[i], bo);
+                if constexpr (XR != 2) py[i] = ldo<T, NT>(V.Y[i], bo);
+            }
         } else {
             if (SPEC) {
                 L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
@@ -1969,12 +2031,37 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             } else {
                 load_params<T, NT>(P, i0, cnt, L, true, true, true);
             }
-            px = ldp<T, NT>(x, i0, cnt); prp = ldp<T, NT>(res_prev, i0, cnt);
+            px = ldp<T, NT>(x, i0, cnt);
+            if constexpr (XR != 2) prp = ldp<T, NT>(res_prev, i0, cnt);
 #pragma unroll
             for (int i = 0; i < MM; ++i)
-                if (i < m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
+                if (i < m) {
+                    ps[i] = ldp<T, NT>(V.S[i], i0, cnt);
+                    if constexpr (XR != 2) py[i] = ldp<T, NT>(V.Y[i], i0, cnt);
+                }
         }
-        if constexpr (XR) {
+        if constexpr (XR == 2) {
+            // ... and the residuals re-evaluated at those iterates instead of read: the same operations on the
+            // same inputs as when they were first computed (gamma, mu, mu*y have not changed since: any
+            // iteration that changes them leaves this mode), so again the same bits
+            Pack<T> rr[MM + 1];
+#pragma unroll
+            for (int i = 0; i <= MM; ++i)
+#pragma unroll
+                for (int e = 0; e < PackN<T>::N; ++e) {
+                    T zz;
+                    rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gamma, gl, zz);
+                }
+            prp = rr[MM];
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+#pragma unroll
+                for (int e = 0; e < PackN<T>::N; ++e) {
+                    const T nx = (i + 1 < MM) ? ps[i + 1].v[e] : px.v[e];
+                    ps[i].v[e] = nx - ps[i].v[e];
+                    py[i].v[e] = rr[i + 1].v[e] - rr[i].v[e];
+                }
+        } else if constexpr (XR == 1) {
             // history kept as ITERATES: V.S[i], V.Y[i] are the snapshots x_{k-MM+i}, res_{k-MM+i} (x and res_prev the
             // newest), and the pairs are their successive differences — the very subtractions that produced the
             // stored s and y (s = x_d - x, y = res - res_prev), so the same bits, for two write streams less
@@ -2037,13 +2124,14 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         }
         if constexpr (O32) {
-            sto<T, NT>(x_d, bo, pxd); if (z) sto<T, NT>(z, bo, pz); sto<T, NT>(res, bo, pr);
-            if constexpr (!XR) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }
+            sto<T, NT>(x_d, bo, pxd); if (z) sto<T, NT>(z, bo, pz);
+            if (XR != 2 || res) sto<T, NT>(res, bo, pr);
+            if constexpr (XR == 0) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }
         } else {
             stp<T, NT>(x_d, i0, cnt, pxd);
             if (z) stp<T, NT>(z, i0, cnt, pz);
-            stp<T, NT>(res, i0, cnt, pr);
-            if constexpr (!XR) {
+            if (XR != 2 || res) stp<T, NT>(res, i0, cnt, pr);
+            if constexpr (XR == 0) {
                 stp<T, NT>(s_new, i0, cnt, pss);
                 stp<T, NT>(y_new, i0, cnt, pyy);
             }

@@ -316,7 +316,7 @@ template <class T> class Solver final : public SolverBase {
         switch (which) {
         case 0: copy_out(out, X_[xc].p, n); break;
         case 1: ensure_z(); copy_out(out, Z_[zc].p, n); break;
-        case 2: copy_out(out, RES_[rc].p, n); break;
+        case 2: ensure_z(); copy_out(out, RES_[rc].p, n); break;
         case 3:
             if (!gx_valid) { algrad(X_[xc].p, GX_.p, SL_AUX); gx_valid = true; }
             copy_out(out, GX_.p, n); break;
@@ -603,9 +603,16 @@ template <class T> class Solver final : public SolverBase {
     // same bits: s = x_d - x, y = res - res_prev are re-formed by the very subtraction that made them) and
     // stops WRITING s and y (two of its dearest streams).  The first iteration that is not a plain one
     // turns the snapshots back into pairs (k_pairs_from_snapshots) and the classic kernels take over.
+    // One step further (headline family, after CM+1 such iterations): the residual of an iterate is a function
+    // of that iterate alone (res = x - prox(x - gamma grad L(x)), with gamma, mu, mu*y fixed along the run), so
+    // the fused pass re-evaluates the CM+1 residuals from the CM+1 iterates instead of reading them, and
+    // stops writing res as well: reads CM+1 iterates + q, b, mu, mu*y, writes x_d.  Same operations on the
+    // same inputs as when each residual was first computed -> the same bits.
     int xr_run_ = 0;             // consecutive plain, pair-inserting iterations so far
-    int xr_env_ = 1, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
+    int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
+    bool rh_stale_ = false;      // ... and the residual ring was not written either during this run
+    bool res_valid = true;       // RES_[rc] holds the residual of the current state
     void materialize_pairs() {
         if (!sy_stale_) return;
         SnapVecs<T, CM> V;
@@ -615,7 +622,13 @@ template <class T> class Solver final : public SolverBase {
             V.RH[i] = RES_[(rc - CM + i + NRR) % NRR].p;
         }
         for (int i = 0; i < CM; ++i) { V.S[i] = S_[order[CM - 1 - i]].p; V.Y[i] = Y_[order[CM - 1 - i]].p; }
-        launch(C_MISC, k_pairs_from_snapshots<T, CM>, grid, V, n);
+        if (rh_stale_) {
+            // (must run before gamma changes: the residuals are re-evaluated with the gamma of this run)
+            launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, P, gamma, RES_[rc].p, Z_[zc].p, n);
+            res_valid = true; z_valid = true;
+        } else {
+            launch(C_MISC, k_pairs_from_snapshots<T, CM>, grid, V, n);
+        }
         sy_stale_ = false;
     }
     int xc = 0, rc = 0, zc = 0;
@@ -852,11 +865,12 @@ template <class T> class Solver final : public SolverBase {
     // z of the CURRENT state into Z_[zc] if the last fused pass skipped its store:
     //   z = prox_{gamma g}(x - gamma grad L(x))   — the arithmetic of k_algrad_elem + k_fbstep, which the fused
     //   passes reproduce bit for bit (test_fused_equals_generic_bitwise)
+    // (likewise the residual res = x - z into RES_[rc] when the pass did not store it)
     void ensure_z() {
-        if (z_valid) return;
+        if (z_valid && res_valid) return;
         algrad(X_[xc].p, D_.p, SL_AUX);                  // scratch gradient: GX_/GZ_ keep their meaning
-        fbstep(X_[xc].p, D_.p, gamma, Z_[zc].p, nullptr, SL_ZS);
-        z_valid = true;
+        fbstep(X_[xc].p, D_.p, gamma, Z_[zc].p, res_valid ? (T*)nullptr : RES_[rc].p, SL_ZS);
+        z_valid = true; res_valid = true;
     }
     // ymask (row-sharded dense c only, where x-space quantities are computed in full by every rank): the
     // slots that are sums over THIS rank's constraint rows and must be added up; the others count once
@@ -1383,8 +1397,8 @@ template <class T> class Solver final : public SolverBase {
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;
         last_nbt = 0; last_fused = false; tau = T(0); last_ys = T(0); fbe_last = T(0);
-        xc = 0; rc = 0; zc = 0; z_valid = true; xr_run_ = 0; sy_stale_ = false;
-        xr_env_ = std::getenv("BZ_XR") ? std::atoi(std::getenv("BZ_XR")) : 1;
+        xc = 0; rc = 0; zc = 0; z_valid = true; xr_run_ = 0; sy_stale_ = false; rh_stale_ = false; res_valid = true;
+        xr_env_ = std::getenv("BZ_XR") ? std::atoi(std::getenv("BZ_XR")) : 2;
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1446,6 +1460,7 @@ template <class T> class Solver final : public SolverBase {
     }
 
     void display() {
+        ensure_z();
         launch(C_MISC, k_absmax<T>, grid, (const T*)RES_[rc].p, n, parts_.p, (int)SL_AUX);
         gather(SL_AUX, 1, 1u);
         auto v = collect({SL_AUX}, 1u);
@@ -1477,7 +1492,7 @@ template <class T> class Solver final : public SolverBase {
         constexpr int NFC = 10 + 4 * CM + 2;                          // slots of k_fused_compact
         static_assert(SL_TRIAL + NFC <= SL_AUX, "k_fused_compact's slots overlap the next group");
         const int m_at_trial = (int)order.size();
-        bool tail_used = false, z_skipped = false;
+        bool tail_used = false, z_skipped = false, res_skipped = false;
         unsigned long long tail_ticket = 0;
         bool gram_from_trial = false;
         tau = T(1);
@@ -1507,9 +1522,25 @@ template <class T> class Solver final : public SolverBase {
             z_skipped = zstore == nullptr;
             static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
             const bool off32 = off32_env && spec && (double)vcap * sizeof(T) < 4.0e9;
-            const bool xr = xr_env_ && off32 && xr_run_ >= CM && (int)order.size() == CM;
+            // 0: stored pairs; 1: pairs re-formed from the iterate / residual rings; 2: residuals re-evaluated too
+            const int xr = !(xr_env_ && off32 && xr_run_ >= CM && (int)order.size() == CM) ? 0
+                           : (xr_env_ >= 2 && xr_run_ >= CM + 1) ? 2 : 1;
             if (sy_stale_ && !xr) materialize_pairs();
-            if (xr) {
+            if (xr != 2 && !res_valid) ensure_z();
+            if (xr == 2) {
+                CompactVecs<T, CM> XV;
+                XV.m = CM;
+                for (int i = 0; i < CM; ++i) { XV.S[i] = X_[(xc - CM + i + NXR) % NXR].p; XV.Y[i] = nullptr; }
+                if (nt)
+                    launch(C_FUSED, k_fused_compact<T, CM, true, true, true, 2>, gfc, XV, CC, (const T*)X_[xp].p,
+                           (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n,
+                           parts_.p, (int)SL_TRIAL);
+                else
+                    launch(C_FUSED, k_fused_compact<T, CM, false, true, true, 2>, gfc, XV, CC, (const T*)X_[xp].p,
+                           (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n,
+                           parts_.p, (int)SL_TRIAL);
+                sy_stale_ = true; rh_stale_ = true; res_skipped = true;
+            } else if (xr) {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
                 for (int i = 0; i < CM; ++i) {
@@ -1517,11 +1548,11 @@ template <class T> class Solver final : public SolverBase {
                     XV.Y[i] = RES_[(rc - CM + i + NRR) % NRR].p;
                 }
                 if (nt)
-                    launch(C_FUSED, k_fused_compact<T, CM, true, true, true, true>, gfc, XV, CC, (const T*)X_[xp].p,
+                    launch(C_FUSED, k_fused_compact<T, CM, true, true, true, 1>, gfc, XV, CC, (const T*)X_[xp].p,
                            (const T*)RES_[rp].p, P, gamma, X_[xd].p, zstore, RES_[rn].p, (T*)nullptr, (T*)nullptr, n, parts_.p,
                            (int)SL_TRIAL);
                 else
-                    launch(C_FUSED, k_fused_compact<T, CM, false, true, true, true>, gfc, XV, CC, (const T*)X_[xp].p,
+                    launch(C_FUSED, k_fused_compact<T, CM, false, true, true, 1>, gfc, XV, CC, (const T*)X_[xp].p,
                            (const T*)RES_[rp].p, P, gamma, X_[xd].p, zstore, RES_[rn].p, (T*)nullptr, (T*)nullptr, n, parts_.p,
                            (int)SL_TRIAL);
                 sy_stale_ = true;
@@ -1547,6 +1578,7 @@ template <class T> class Solver final : public SolverBase {
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
             n_grad += 2; n_prox += 1;
         } else if (fused_ok) {
+            if (!res_valid) ensure_z();
             for (int k = 0; k < 10; ++k) slot_n[SL_TRIAL + k] = grid;
             launch(C_FUSED, k_fused_sep<T>, grid, tail, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, gamma,
                    X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, (T*)nullptr, (T*)nullptr, n,
@@ -1555,6 +1587,7 @@ template <class T> class Solver final : public SolverBase {
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false;
             n_grad += 2; n_prox += 1;
         } else {
+            if (!res_valid) ensure_z();
             // x_d = x + d ; gradient at x_d ; state.x = x_d
             if (use_compact)
                 launch(C_TWOLOOP, k_compact_xd<T, CM>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p,
@@ -1621,9 +1654,10 @@ template <class T> class Solver final : public SolverBase {
             const T FBE_new = f_z_upp + g_z;
             // not a plain iteration: z of the state this step started from may be needed (z_curr below), and
             // it must be formed with the gamma of that state
-            if (!z_valid && (halve || !(FBE_new <= threshold || k >= max_bt))) ensure_z();
-            // ... and the classic kernels that finish this iteration need the stored pairs as vectors
+            // ... and the classic kernels that finish this iteration need the stored pairs (and the residual of
+            // that state) as vectors
             if (sy_stale_ && (halve || !(FBE_new <= threshold || k >= max_bt))) materialize_pairs();
+            if ((!z_valid || !res_valid) && (halve || !(FBE_new <= threshold || k >= max_bt))) ensure_z();
             if (halve) {
                 gamma = gamma * T(0.5); ++n_halv;
                 if (gamma < min_gamma)
@@ -1671,9 +1705,11 @@ template <class T> class Solver final : public SolverBase {
         }
         // history as iterates is possible after CM plain iterations in a row that each inserted their pair
         xr_run_ = (fused_this && use_compact && ys > T(0) && xcur == xd) ? xr_run_ + 1 : 0;
+        if (xr_run_ == 0) rh_stale_ = false;       // (whatever broke the run has materialised the pairs above)
         stop_norm_ = v[9];
         xc = xcur; rc = rn; zc = zn;
         z_valid = !(z_skipped && fused_this);      // the generic trial writes z; an accepted fused one may not have
+        res_valid = !(res_skipped && fused_this);  // ... nor res
         last_nbt = nbt; last_fused = fused_this;
         if (fused_this) ++n_fused;
     }

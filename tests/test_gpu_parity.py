@@ -1040,8 +1040,11 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
     (1) once the last five iterations were plain ones, the stored pairs are re-formed from the last six iterates
         kept in the x / res rings (s = x_d - x, y = res - res_prev: the same subtractions) and s, y are no longer
         written; the first iteration that is not plain turns the snapshots back into pairs;
-    (2) z is not stored and is re-materialised on demand.
-    With both off, both on, and each alone, runs that go through gamma halvings, tau backtracks, and — the
+    (2) z is not stored and is re-materialised on demand;
+    (3) BZ_XR=2 (the default): after one more plain iteration the residuals are not read from their ring either but
+        re-evaluated from the six iterates (res = x - prox(x - gamma grad L(x)): the same operations on the same
+        inputs), and res is no longer written.
+    With all off, all on, and each alone, runs that go through gamma halvings, tau backtracks, and — the
     "zero" start run to convergence — skipped pairs and re-entries must produce identical bits."""
     d, dev, orc = make_cfg2(bz, ref, n)
     rng = np.random.default_rng(9)
@@ -1050,7 +1053,7 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
     x0 = rng.standard_normal(n) * 0.05 if start == "random" else np.zeros(n)
     runs = []
     try:
-        for xr, skipz in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "1")):
+        for xr, skipz in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "1"), ("2", "1"), ("2", "0")):
             os.environ["BZ_XR"], os.environ["BZ_SKIPZ"] = xr, skipz
             prob = bz.Problem(*dev, n, n, np.float64)
             prob.set_multipliers(mu, y)
@@ -1061,6 +1064,8 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
                 prob.panoc_step()
                 if k % 37 == 5:
                     zs.append(prob.panoc_vector("z"))            # mid-run read-outs must not disturb anything
+                if k % 41 == 17:
+                    zs.append(prob.panoc_vector("res"))
             st = prob.panoc_stats()
             runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars(), zs,
                          (st.n_backtracks, st.n_gamma_halvings, st.n_lbfgs_skips, st.n_fused_iters), prob.profile()["misc"]["launches"]))
@@ -1079,3 +1084,4 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
     if start == "zero":
         assert base[5][2] > 0                            # pairs were skipped: the snapshots had to become pairs again
         assert runs[1][6] > runs[0][6]                   # ... by k_pairs_from_snapshots (category misc)
+        assert runs[4][6] > runs[0][6]                   # ... or k_pairs_from_iterates

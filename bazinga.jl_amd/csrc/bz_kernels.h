@@ -61,6 +61,7 @@ template <class T> struct ElemParams {
     T D_lo, D_hi;
     const T* D_lo_vec;
     const T* D_hi_vec;
+    T mu_uniform;          // the value of every mu[i] when the penalties are uniform (k_uniform_probe), else unused
 };
 
 // ---------------------------------------------------------------------------
@@ -295,6 +296,13 @@ template <class T> __device__ __forceinline__ T proj_D(int kind, T t, T lo, T hi
     return t < lo ? lo : (t > hi ? hi : t);   // IndBox prox: if x<lb lb elseif x>ub ub else x
 }
 
+// min(max(v, lo), hi) on the min/max units (2 instructions; the compare-and-select form is 6 in fp64).  For
+// lo <= hi it is the value `v < lo ? lo : (v > hi ? hi : v)` for every non-NaN v (up to the sign of a zero
+// result when a bound is itself a zero); a NaN v comes out as `lo`, so this form is only used where the
+// result is immediately subtracted from v (v - clamp(v) is NaN either way).
+__device__ __forceinline__ double clamp_mm(double v, double lo, double hi) { return __builtin_fmin(__builtin_fmax(v, lo), hi); }
+__device__ __forceinline__ float clamp_mm(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
+
 template <class T> struct ALOut {
     T grad, fterm, pterm;
 };
@@ -307,7 +315,7 @@ __device__ __forceinline__ ALOut<T> al_elem(int f_kind, int D_kind, T x, T q, T 
     ALOut<T> o;
     T cx = x;                       // eval!(cx, c, x)
     T t = cx + muy;                 // yupd = cx + mu*y
-    T s = proj_D(D_kind, t, lo, hi, tp, pos);
+    T s = (D_kind == BZ_D_BOX) ? clamp_mm(t, lo, hi) : proj_D(D_kind, t, lo, hi, tp, pos);
     t = t - s;                      // yupd -= s
     o.pterm = (t * t) / mu;         // (yupd^2)/mu, summed then halved
     T yupd = t / mu;                // yupd /= mu
@@ -380,7 +388,7 @@ __device__ __forceinline__ T prox_elem(int g_kind, T y, T gl, T u, T lo, T hi, T
         break;
     }
     case BZ_G_NORM_L1: {            // ProximalOperators.NormL1
-        z = y + (y <= -gl ? gl : (y >= gl ? -gl : -y));
+        z = y - clamp_mm(y, -gl, gl);       // = y + (y <= -gl ? gl : (y >= gl ? -gl : -y)), bit for bit (gl > 0)
         gterm = z > T(0) ? z : -z;
         break;
     }
@@ -1974,7 +1982,10 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, ElemParams<T> P, T gamma, T* __restrict
 //           in registers (s_new, y_new not written)
 //   XR = 2: as 1, and the residuals are not read either but re-evaluated from the iterates (resid_elem):
 //           reads the MM+1 iterates, q, b, mu, mu*y ; writes x_d only (res too if `res` is not null)
-template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, int XR = 0>
+//   UNI = 1: every mu[i] is the same number (P.mu_uniform; alps.jl:42 from a start with c(x0) in D, and
+//            alps.jl:97 scales all of them alike) -> not streamed ; UNI = 2: and mu*y = 0 (first subproblem from
+//            y0 = 0) -> not streamed either.  Same operands, same operations (the + 0 stays), so the same bits.
+template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, int XR = 0, int UNI = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
@@ -2002,17 +2013,41 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+    // XR = 2 reads few enough streams (MM+1 iterates + 2..4 parameter vectors) to keep the NEXT pack's loads in
+    // flight while this pack's ~800 instructions run: a one-deep software pipeline in registers
+    constexpr bool PIPE = SPEC && OFF32 && XR == 2;
+    struct Stage { Pack<T> q, b, mu, muy, px, ps[MM]; };
+    auto load_stage = [&](Stage& S, unsigned bo) {
+        asm volatile("" : "+v"(bo));
+        S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo);
+        if constexpr (UNI < 1) S.mu = ldo<T, NT>(P.mu, bo);
+        if constexpr (UNI < 2) S.muy = ldo<T, NT>(P.muy, bo);
+        S.px = ldo<T, NT>(x, bo);
+#pragma unroll
+        for (int i = 0; i < MM; ++i) S.ps[i] = ldo<T, NT>(V.S[i], bo);
+    };
+    auto body = [&](const int64_t i0, const auto cnt_, const auto staged_, const Stage& SG) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         // full chunks of a vector shorter than 4 GiB: every stream is (scalar base, one shared 32-bit offset)
         constexpr bool O32 = SPEC && OFF32 && !std::is_integral<std::remove_cv_t<decltype(cnt_)>>::value;
+        constexpr bool STAGED = std::remove_cv_t<decltype(staged_)>::value;
         unsigned bo = (unsigned)(i0 * (int64_t)sizeof(T));
         if constexpr (O32) asm volatile("" : "+v"(bo));      // opaque: no per-stream 64-bit pointer induction variables
         ElemLoads<T> L;
         Pack<T> px, prp, ps[MM], py[MM], d;
-        if constexpr (O32) {
+        if constexpr (STAGED) {
+            L.q = SG.q; L.b = SG.b;
+            if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = SG.mu;
+            if constexpr (UNI >= 2) L.muy = splat(T(0)); else L.muy = SG.muy;
+            L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
+            L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
+            px = SG.px;
+#pragma unroll
+            for (int i = 0; i < MM; ++i) ps[i] = SG.ps[i];
+        } else if constexpr (O32) {
             L.q = ldo<T, NT>(P.q, bo); L.b = ldo<T, NT>(P.b, bo);
-            L.mu = ldo<T, NT>(P.mu, bo); L.muy = ldo<T, NT>(P.muy, bo);
+            if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = ldo<T, NT>(P.mu, bo);
+            if constexpr (UNI >= 2) L.muy = splat(T(0)); else L.muy = ldo<T, NT>(P.muy, bo);
             L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
             L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
             px = ldo<T, NT>(x, bo);
@@ -2025,7 +2060,8 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         } else {
             if (SPEC) {
                 L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
-                L.mu = ldp<T, NT>(P.mu, i0, cnt); L.muy = ldp<T, NT>(P.muy, i0, cnt);
+                if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = ldp<T, NT>(P.mu, i0, cnt);
+                if constexpr (UNI >= 2) L.muy = splat(T(0)); else L.muy = ldp<T, NT>(P.muy, i0, cnt);
                 L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
                 L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
             } else {
@@ -2136,7 +2172,32 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                 stp<T, NT>(y_new, i0, cnt, pyy);
             }
         }
-    });
+    };
+    if constexpr (PIPE) {
+        // the chunk -> thread map of bz_for_chunks, with the loads of chunk c + stride issued before chunk c is
+        // consumed (past the end a thread re-requests the last full chunk: no branch, nothing out of bounds)
+        constexpr int N = PackN<T>::N;
+        const int64_t nfull = n / N;
+        const int64_t stride = (int64_t)gridDim.x * BLOCK;
+        int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        // two packs ahead: with one, a wave has 8..10 KB in flight and the pass is bound by latency x concurrency
+        Stage cur, nx1, nx2;
+        auto clampc = [&](int64_t k) { return k < nfull ? k : (nfull - 1); };
+        if (c < nfull) {
+            load_stage(cur, (unsigned)(c * N * (int64_t)sizeof(T)));
+            load_stage(nx1, (unsigned)(clampc(c + stride) * N * (int64_t)sizeof(T)));
+        }
+        for (; c < nfull; c += stride) {
+            load_stage(nx2, (unsigned)(clampc(c + 2 * stride) * N * (int64_t)sizeof(T)));
+            body(c * N, std::integral_constant<int, N>{}, std::true_type{}, cur);
+            cur = nx1;
+            nx1 = nx2;
+        }
+        if (c == nfull && nfull * N < n) body(c * N, (int)(n - nfull * N), std::false_type{}, cur);
+    } else {
+        Stage none;
+        bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) { body(i0, cnt_, std::false_type{}, none); });
+    }
     block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
 }
 
@@ -2220,6 +2281,28 @@ k_muy(const T* __restrict__ mu, const T* __restrict__ y, T* __restrict__ muy, in
         st(muy, i0, cnt, o);
     });
     block_reduce_store<2>(acc, 2u, parts, slot0);
+}
+
+// are the penalties uniform, are the scaled multipliers zero?  slots (all max, all >= 0 as the folds assume):
+//   +0 max mu, +1 max (mu[i] != mu[0]), +2 max |mu*y|
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_uniform_probe(const T* __restrict__ mu, const T* __restrict__ muy, int64_t n, double* __restrict__ parts,
+                int slot0) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    const T m0 = mu[0];
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        Pack<T> pm = ld(mu, i0, cnt), py = ld(muy, i0, cnt);
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e)
+            if (e < cnt) {
+                acc[0] = nanmax(acc[0], (double)pm.v[e]);
+                acc[1] = nanmax(acc[1], pm.v[e] == m0 ? 0.0 : 1.0);
+                acc[2] = nanmax(acc[2], (double)(py.v[e] < T(0) ? -py.v[e] : py.v[e]));
+            }
+    });
+    block_reduce_store<3>(acc, 7u, parts, slot0);
 }
 
 // dual update with c = Identity (alps.jl:72-84):

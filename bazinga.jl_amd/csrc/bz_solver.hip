@@ -1141,7 +1141,30 @@ template <class T> class Solver final : public SolverBase {
         auto v = collect({SL_OUTER, SL_OUTER + 1}, 2u);
         if (v[1] > 0.0) throw Error(BZ_ERR_MU, "parameters `mu` must be positive");
         musqy = T(0.5) * T(v[0]);
+        // Uniform penalties / zero multipliers (this rank's part of them): the one-pass kernel then takes mu as a
+        // number and does not stream mu (nor mu*y).  alps.jl:42 gives every constraint the same mu when c(x0) is
+        // in D, alps.jl:97 scales them alike, and y0 = 0 holds through the first subproblem — the longest one.
+        uni_ = 0;
+        const int uni_env = std::getenv("BZ_UNI") ? std::atoi(std::getenv("BZ_UNI")) : 2;      // (tests toggle it)
+        if (uni_env && fused_family()) {
+            for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
+            launch(C_MISC, k_uniform_probe<T>, grid_y, (const T*)mu_.p, (const T*)muy_.p, ny, parts_.p, (int)SL_GP);
+            CollectArgs a;
+            a.n = 3; a.maxmask = 7u;
+            for (int k = 0; k < 3; ++k) a.src[k] = ScalarSrc{parts_.p + (size_t)(SL_GP + k) * PSTRIDE, grid_y, 1};
+            auto u = collect_run(a);               // this rank's values: no exchange (every form gives the same bits)
+            if (u[1] == 0.0 && u[0] > 0.0) {
+                uni_ = (u[2] == 0.0 && uni_env >= 2) ? 2 : 1;
+                P.mu_uniform = (T)u[0];
+            }
+        }
     }
+    // the oracle family the specialised one-pass kernel serves (see step())
+    bool fused_family() const {
+        return desc.c_kind == BZ_C_IDENTITY && !slack && desc.f_kind == BZ_F_DIAG_QUADRATIC &&
+               desc.g_kind == BZ_G_NORM_L1 && desc.D_kind == BZ_D_BOX && !P.D_lo_vec && !P.D_hi_vec && ny == n;
+    }
+    int uni_ = 0;
 
     // --------------------------------------------------------------- L-BFGS
     void alloc_history() {
@@ -1499,7 +1522,7 @@ template <class T> class Solver final : public SolverBase {
         const int xp = xc, xd = (xc + 1) % NXR, xb = (xc + 2) % NXR;
         const int rp = rc, rn = (rc + 1) % NRR, zp = zc, zn = 1 - zc;
         int xcur = xd;
-        bool have_trial = false, fused_this = false;
+        bool have_trial = false, fused_this = false, reset_this = false;
         if (fused_ok && use_compact) {
             // 176 VGPRs -> two 256-thread blocks per CU: one resident round of blocks (each block pays the
             // coefficient prologue and a 20-slot reduction epilogue once)
@@ -1510,7 +1533,6 @@ template <class T> class Solver final : public SolverBase {
             // Cache.  Measured fused-pass times, default policy vs non-temporal: n = 1.25e6 (210 MB) 39.0 / 44.5 us,
             // 1.8e6 (302 MB) 51.0 / 60.4, 2.5e6 (420 MB) 90.1 / 81.5, 5e6 (840 MB) 171 / 159, 1e7 322 / 314.
             static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
-            const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * (2 * CM + 11) > 360e6;
             // headline family with everything uniform fixed at compile time (see the kernel)
             static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
             const bool spec = spec_env && desc.f_kind == BZ_F_DIAG_QUADRATIC && desc.g_kind == BZ_G_NORM_L1 &&
@@ -1527,18 +1549,21 @@ template <class T> class Solver final : public SolverBase {
                            : (xr_env_ >= 2 && xr_run_ >= CM + 1) ? 2 : 1;
             if (sy_stale_ && !xr) materialize_pairs();
             if (xr != 2 && !res_valid) ensure_z();
+            const int uni = xr == 2 ? uni_ : 0;
+            // (the vectors this pass touches: history + x_d + z + q, b, mu, mu*y (+ res, s, y))
+            const int nvec = (xr == 2 ? CM + 6 - uni : 2 * CM + 9) + (zstore ? 1 : 0);
+            const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * nvec > 340e6;
             if (xr == 2) {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
                 for (int i = 0; i < CM; ++i) { XV.S[i] = X_[(xc - CM + i + NXR) % NXR].p; XV.Y[i] = nullptr; }
-                if (nt)
-                    launch(C_FUSED, k_fused_compact<T, CM, true, true, true, 2>, gfc, XV, CC, (const T*)X_[xp].p,
-                           (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n,
-                           parts_.p, (int)SL_TRIAL);
-                else
-                    launch(C_FUSED, k_fused_compact<T, CM, false, true, true, 2>, gfc, XV, CC, (const T*)X_[xp].p,
-                           (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n,
-                           parts_.p, (int)SL_TRIAL);
+#define BZ_LAUNCH_FC2(NT_, UNI_)                                                                                  \
+    launch(C_FUSED, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,           \
+           (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p,     \
+           (int)SL_TRIAL)
+                if (nt) { if (uni == 2) BZ_LAUNCH_FC2(true, 2); else if (uni == 1) BZ_LAUNCH_FC2(true, 1); else BZ_LAUNCH_FC2(true, 0); }
+                else { if (uni == 2) BZ_LAUNCH_FC2(false, 2); else if (uni == 1) BZ_LAUNCH_FC2(false, 1); else BZ_LAUNCH_FC2(false, 0); }
+#undef BZ_LAUNCH_FC2
                 sy_stale_ = true; rh_stale_ = true; res_skipped = true;
             } else if (xr) {
                 CompactVecs<T, CM> XV;
@@ -1664,7 +1689,7 @@ template <class T> class Solver final : public SolverBase {
                     std::fprintf(stderr, "Warning: stepsize `gamma` became too small (%g)\n", (double)gamma);
                 sigma = sigma * T(2);   // (as upstream: sigma is updated, the threshold is kept)
                 lbfgs_reset();
-                fused_this = false;
+                fused_this = false; reset_this = true;
                 continue;
             }
             if (FBE_new <= threshold || k >= max_bt) break;
@@ -1703,8 +1728,17 @@ template <class T> class Solver final : public SolverBase {
             ++n_skips;
             materialize_pairs();         // (history as iterates: the window stops being contiguous here)
         }
-        // history as iterates is possible after CM plain iterations in a row that each inserted their pair
-        xr_run_ = (fused_this && use_compact && ys > T(0) && xcur == xd) ? xr_run_ + 1 : 0;
+        // A tau-backtracked point sits in the blend buffer: trade the two buffers so that the accepted iterate is
+        // the next one of the ring whatever produced it — the stored pairs stay the successive differences of
+        // the ring's last iterates (and residuals), and the run below goes on through backtracks
+        if (xcur == xb && fused_ok && use_compact) {
+            std::swap(X_[xd].p, X_[xb].p);
+            std::swap(X_[xd].n, X_[xb].n);
+            xcur = xd;
+        }
+        // history as iterates is possible after CM iterations in a row that each inserted their pair, with no
+        // change of gamma (which resets the memory) in between
+        xr_run_ = (fused_ok && use_compact && ys > T(0) && xcur == xd && !reset_this) ? xr_run_ + 1 : 0;
         if (xr_run_ == 0) rh_stale_ = false;       // (whatever broke the run has materialised the pairs above)
         stop_norm_ = v[9];
         xc = xcur; rc = rn; zc = zn;

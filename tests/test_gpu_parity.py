@@ -1043,7 +1043,9 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
     (2) z is not stored and is re-materialised on demand;
     (3) BZ_XR=2 (the default): after one more plain iteration the residuals are not read from their ring either but
         re-evaluated from the six iterates (res = x - prox(x - gamma grad L(x)): the same operations on the same
-        inputs), and res is no longer written.
+        inputs), and res is no longer written;
+    (4) BZ_UNI: uniform penalties mu (and mu*y = 0, the "zero" start) are detected and passed as numbers instead of
+        being streamed.
     With all off, all on, and each alone, runs that go through gamma halvings, tau backtracks, and — the
     "zero" start run to convergence — skipped pairs and re-entries must produce identical bits."""
     d, dev, orc = make_cfg2(bz, ref, n)
@@ -1053,8 +1055,9 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
     x0 = rng.standard_normal(n) * 0.05 if start == "random" else np.zeros(n)
     runs = []
     try:
-        for xr, skipz in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "1"), ("2", "1"), ("2", "0")):
-            os.environ["BZ_XR"], os.environ["BZ_SKIPZ"] = xr, skipz
+        for xr, skipz, uni in (("0", "0", "0"), ("1", "1", "0"), ("1", "0", "0"), ("0", "1", "0"), ("2", "1", "0"),
+                               ("2", "0", "0"), ("2", "1", "1"), ("2", "1", "2")):
+            os.environ["BZ_XR"], os.environ["BZ_SKIPZ"], os.environ["BZ_UNI"] = xr, skipz, uni
             prob = bz.Problem(*dev, n, n, np.float64)
             prob.set_multipliers(mu, y)
             prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps)).c_opts(), x0)
@@ -1073,6 +1076,7 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
     finally:
         os.environ.pop("BZ_XR", None)
         os.environ.pop("BZ_SKIPZ", None)
+        os.environ.pop("BZ_UNI", None)
     base = runs[0]
     for r in runs[1:]:
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]) and np.array_equal(r[2], base[2])

@@ -20,9 +20,10 @@ BZ_G_NORM_LP_NONNEG, BZ_G_NORM_LP_BOX = 6, 7
 BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
 BZ_D_VC_PAIRS, BZ_D_CC_PAIRS, BZ_D_EITHEROR_PAIRS, BZ_D_XOR_PAIRS = 3, 4, 5, 6
-NUM_KERNEL_CATEGORIES = 12
+NUM_KERNEL_CATEGORIES = 13
 KERNEL_CATEGORIES = ("k_axpy_dot", "k_fused_sep", "al_gradient", "fb_step",
-                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv", "k_twoloop_persist", "k_gemv_t_mfma")
+                     "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv", "k_twoloop_persist", "k_gemv_t_mfma",
+                     "k_fused_iterates")
 
 
 class CtxOpts(C.Structure):

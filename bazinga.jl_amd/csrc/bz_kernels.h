@@ -303,6 +303,23 @@ template <class T> __device__ __forceinline__ T proj_D(int kind, T t, T lo, T hi
 __device__ __forceinline__ double clamp_mm(double v, double lo, double hi) { return __builtin_fmin(__builtin_fmax(v, lo), hi); }
 __device__ __forceinline__ float clamp_mm(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
 
+// a / b for a divisor b that is uniform over the launch, given rb = RN(1/b) (one true division per thread):
+// two Markstein refinement steps, q <- q + RN(a - b q) rb with the remainder exact in an fma.  After the
+// first step q is within one ulp of a/b; with rb the correctly rounded reciprocal the second step then
+// returns the correctly rounded quotient (Markstein 1990, Thm. 8.5 in Muller et al.'s Handbook) — the bits of
+// the hardware division sequence (v_div_scale/rcp/5 fma/v_div_fmas/v_div_fixup) in half the instructions.
+// Holds for finite a and quotients in the normal range, which is where the solver works (an infinite a gives
+// NaN instead of inf: either way the iterate is lost).  The forms with and without it are compared bit for
+// bit in test_history_as_iterates_and_lazy_z_are_bitwise_neutral.
+__device__ __forceinline__ double div_u(double a, double b, double rb) {
+    double q = a * rb;
+    double e = __builtin_fma(-b, q, a);
+    q = __builtin_fma(e, rb, q);
+    e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, rb, q);
+}
+__device__ __forceinline__ float div_u(float a, float b, float) { return a / b; }
+
 template <class T> struct ALOut {
     T grad, fterm, pterm;
 };
@@ -311,14 +328,14 @@ template <class T> struct ALOut {
 // c = Identity and an element-wise f.
 template <class T>
 __device__ __forceinline__ ALOut<T> al_elem(int f_kind, int D_kind, T x, T q, T b, T mu, T muy,
-                                            T lo, T hi, T tp = T(0), int pos = 0) {
+                                            T lo, T hi, T tp = T(0), int pos = 0, bool udiv = false, T rmu = T(0)) {
     ALOut<T> o;
     T cx = x;                       // eval!(cx, c, x)
     T t = cx + muy;                 // yupd = cx + mu*y
     T s = (D_kind == BZ_D_BOX) ? clamp_mm(t, lo, hi) : proj_D(D_kind, t, lo, hi, tp, pos);
     t = t - s;                      // yupd -= s
-    o.pterm = (t * t) / mu;         // (yupd^2)/mu, summed then halved
-    T yupd = t / mu;                // yupd /= mu
+    o.pterm = udiv ? div_u(t * t, mu, rmu) : (t * t) / mu;         // (yupd^2)/mu, summed then halved
+    T yupd = udiv ? div_u(t, mu, rmu) : t / mu;                    // yupd /= mu
     T dfx;
     if (f_kind == BZ_F_DIAG_QUADRATIC) {
         T qx = q * x;
@@ -1791,6 +1808,14 @@ template <int MM> struct CompactCoef {
     double H0;
 };
 
+// acc + a*b for the inner products that only the compact form's own kernels produce (Gram products, p, w) and
+// for the linear combination d: one fused multiply-add in fp64 (one rounding instead of two, half the
+// instructions); fp32 keeps the rounded product, as the oracle's fp32 arithmetic has it
+__device__ __forceinline__ double mul_acc(double a, double b, double acc) { return __builtin_fma(a, b, acc); }
+__device__ __forceinline__ double mul_acc(float a, float b, double acc) { return acc + (double)(a * b); }
+__device__ __forceinline__ double mul_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float mul_add(float a, float b, float c) { float t = a * b; return c + t; }
+
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
 template <class T, int MM>
 __global__ void __launch_bounds__(BLOCK)
@@ -1810,8 +1835,8 @@ k_gram_dots(CompactVecs<T, MM> V, const T* __restrict__ res, int64_t n, double* 
                 for (int e = 0; e < PackN<T>::N; ++e)
                     if (e < cnt) {
                         const T v = T(-1) * pr.v[e];
-                        acc[i] += (double)(ps.v[e] * v);
-                        acc[MM + i] += (double)(py.v[e] * v);
+                        acc[i] = mul_acc(ps.v[e], v, acc[i]);
+                        acc[MM + i] = mul_acc(py.v[e], v, acc[MM + i]);
                     }
             }
         }
@@ -1835,10 +1860,10 @@ __device__ __forceinline__ void compact_d(int m, T H0, const T (&u1)[MM],
         T a = H0 * (T(-1) * pres.v[e]);
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < m) { T t = u1[i] * ps[i].v[e]; a = a + t; }
+            if (i < m) a = mul_add(u1[i], ps[i].v[e], a);
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < m) { T t = u2h[i] * py[i].v[e]; a = a + t; }
+            if (i < m) a = mul_add(u2h[i], py[i].v[e], a);
         d.v[e] = a;
     }
 }
@@ -1882,8 +1907,8 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
 #pragma unroll
                 for (int e = 0; e < PackN<T>::N; ++e)
                     if (e < cnt) {
-                        acc[i] += (double)(ps.v[e] * pn.v[e]);
-                        acc[MM + i] += (double)(py.v[e] * pn.v[e]);
+                        acc[i] = mul_acc(ps.v[e], pn.v[e], acc[i]);
+                        acc[MM + i] = mul_acc(py.v[e], pn.v[e], acc[MM + i]);
                     }
             }
         }
@@ -1922,8 +1947,9 @@ __global__ void __launch_bounds__(BLOCK) k_pairs_from_snapshots(SnapVecs<T, MM> 
 // re-evaluating it at an iterate the rings still hold gives back the bits of the residual computed then
 template <class T>
 __device__ __forceinline__ T resid_elem(int fk, int dk, int gk, T xv, const ElemLoads<T>& L, int e, T gamma, T gl,
-                                        T& zz) {
-    ALOut<T> o = al_elem(fk, dk, xv, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+                                        T& zz, bool udiv = false, T rmu = T(0)) {
+    ALOut<T> o = al_elem(fk, dk, xv, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0,
+                         udiv, rmu);
     T t = gamma * o.grad;
     T y = xv - t;
     T gterm;
@@ -2009,6 +2035,10 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         asm volatile("" : "+v"(gl));
         asm volatile("" : "+v"(gamma));
     }
+    // uniform penalty in fp64: the 8 divisions by mu per element (and the one by gamma) go through div_u
+    constexpr bool UDIV = UNI >= 1 && sizeof(T) == 8;
+    T rmu = T(0), rgam = T(0);
+    if constexpr (UDIV) { rmu = T(1) / P.mu_uniform; rgam = T(1) / gamma; }
     constexpr int NS = 10 + 4 * MM + 2;
     double acc[NS];
 #pragma unroll
@@ -2086,7 +2116,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
 #pragma unroll
                 for (int e = 0; e < PackN<T>::N; ++e) {
                     T zz;
-                    rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gamma, gl, zz);
+                    rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gamma, gl, zz, UDIV, rmu);
                 }
             prp = rr[MM];
 #pragma unroll
@@ -2117,17 +2147,17 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         for (int e = 0; e < PackN<T>::N; ++e) {
             T xd = px.v[e] + d.v[e];
             ALOut<T> o1 = al_elem(fk, dk, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu);
             T t = gamma * o1.grad;
             T y = xd - t;
             T gterm;
             T zz = prox_elem(gk, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
             T r = xd - zz;
             ALOut<T> o2 = al_elem(fk, dk, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu);
             T sv = xd - px.v[e];
             T yy = r - prp.v[e];
-            T w = r / gamma;
+            T w = UDIV ? div_u(r, gamma, rgam) : r / gamma;
             w = w - o1.grad;
             w = w + o2.grad;
             pxd.v[e] = xd; pz.v[e] = zz; pr.v[e] = r; pss.v[e] = sv; pyy.v[e] = yy;
@@ -2145,18 +2175,18 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
 #pragma unroll
                 for (int i = 0; i < MM; ++i)
                     if (i < m) {
-                        acc[10 + i] += (double)(ps[i].v[e] * yy);
-                        acc[10 + MM + i] += (double)(py[i].v[e] * yy);
+                        acc[10 + i] = mul_acc(ps[i].v[e], yy, acc[10 + i]);
+                        acc[10 + MM + i] = mul_acc(py[i].v[e], yy, acc[10 + MM + i]);
                     }
                 const T nr = T(-1) * r;
 #pragma unroll
                 for (int i = 0; i < MM; ++i)
                     if (i < m) {
-                        acc[10 + 2 * MM + i] += (double)(ps[i].v[e] * nr);
-                        acc[10 + 3 * MM + i] += (double)(py[i].v[e] * nr);
+                        acc[10 + 2 * MM + i] = mul_acc(ps[i].v[e], nr, acc[10 + 2 * MM + i]);
+                        acc[10 + 3 * MM + i] = mul_acc(py[i].v[e], nr, acc[10 + 3 * MM + i]);
                     }
-                acc[10 + 4 * MM] += (double)(sv * nr);
-                acc[10 + 4 * MM + 1] += (double)(yy * nr);
+                acc[10 + 4 * MM] = mul_acc(sv, nr, acc[10 + 4 * MM]);
+                acc[10 + 4 * MM + 1] = mul_acc(yy, nr, acc[10 + 4 * MM + 1]);
             }
         }
         if constexpr (O32) {

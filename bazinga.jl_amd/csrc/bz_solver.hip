@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(64) k_collect_w(CollectArgs a, double* out) {
 }
 
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
-                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11 };
+                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11, C_FUSED_IT = 12 };
 
 template <class T> class Solver final : public SolverBase {
    public:
@@ -1526,9 +1526,8 @@ template <class T> class Solver final : public SolverBase {
         if (fused_ok && use_compact) {
             // 176 VGPRs -> two 256-thread blocks per CU: one resident round of blocks (each block pays the
             // coefficient prologue and a 20-slot reduction epilogue once)
-            static const int gfc_mult = std::getenv("BZ_GFC") ? std::atoi(std::getenv("BZ_GFC")) : 2;
-            const int gfc = std::min(grid, gfc_mult * std::max(1, num_cus));
-            for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
+            const int gfc_env = std::getenv("BZ_GFC") ? std::atoi(std::getenv("BZ_GFC")) : 0;     // (tests set it)
+            int gfc = std::min(grid, (gfc_env > 0 ? gfc_env : 2) * std::max(1, num_cus));
             // non-temporal loads/stores once the working set (2M + 11 vectors) no longer fits the 256 MB Infinity
             // Cache.  Measured fused-pass times, default policy vs non-temporal: n = 1.25e6 (210 MB) 39.0 / 44.5 us,
             // 1.8e6 (302 MB) 51.0 / 60.4, 2.5e6 (420 MB) 90.1 / 81.5, 5e6 (840 MB) 171 / 159, 1e7 322 / 314.
@@ -1550,6 +1549,12 @@ template <class T> class Solver final : public SolverBase {
             if (sy_stale_ && !xr) materialize_pairs();
             if (xr != 2 && !res_valid) ensure_z();
             const int uni = xr == 2 ? uni_ : 0;
+            // the iterate-history form keeps two packs of loads in flight per wave and runs best with ONE wave per
+            // SIMD (n = 1e7: 134 vs 140 us; 1.25e6: 28.5 vs 30.2 us): the wave has the vector ALU to itself and
+            // the 32-scalar epilogue runs half as often.  (A different grid is a different summation tree: the
+            // forms then agree to rounding, not bit for bit — BZ_GFC pins one grid for all of them.)
+            if (xr == 2 && gfc_env <= 0) gfc = std::min(grid, std::max(1, num_cus));
+            for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
             // (the vectors this pass touches: history + x_d + z + q, b, mu, mu*y (+ res, s, y))
             const int nvec = (xr == 2 ? CM + 6 - uni : 2 * CM + 9) + (zstore ? 1 : 0);
             const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * nvec > 340e6;
@@ -1558,7 +1563,7 @@ template <class T> class Solver final : public SolverBase {
                 XV.m = CM;
                 for (int i = 0; i < CM; ++i) { XV.S[i] = X_[(xc - CM + i + NXR) % NXR].p; XV.Y[i] = nullptr; }
 #define BZ_LAUNCH_FC2(NT_, UNI_)                                                                                  \
-    launch(C_FUSED, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,           \
+    launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,        \
            (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p,     \
            (int)SL_TRIAL)
                 if (nt) { if (uni == 2) BZ_LAUNCH_FC2(true, 2); else if (uni == 1) BZ_LAUNCH_FC2(true, 1); else BZ_LAUNCH_FC2(true, 0); }

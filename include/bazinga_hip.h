@@ -183,7 +183,7 @@ typedef struct {
                                    dependent reductions per application);
                                 1: compact (Byrd-Nocedal-Schnabel) representation (M <= 5): no sequential
                                    reductions, so for c = Identity with an element-wise f the whole
-                                   iteration is ONE streaming pass over 2M+8..2M+10 vectors and one reduction
+                                   iteration is ONE streaming pass over M+4..2M+10 vectors and one reduction
                                    phase (one cross-GPU exchange) instead of 2M+1.  The same operator, an
                                    alternate rounding: its iterates track the fp64 oracle as closely as the
                                    two-loop kernels' do;
@@ -286,10 +286,12 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
 /* category: 0 k_axpy_dot (two-loop step), 1 k_fused_sep (fused separable iteration),
  *           2 AL gradient, 3 forward-backward step, 4 L-BFGS update/stop norm,
  *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot),
- *           9 dense GEMV kernels (vector ALU), 10 k_twoloop_persist, 11 k_gemv_t_mfma.
+ *           9 dense GEMV kernels (vector ALU), 10 k_twoloop_persist, 11 k_gemv_t_mfma,
+ *           12 k_fused_compact in its steady-state form (history kept as iterates: reads the M+1 last
+ *              iterates and the problem data, writes x_d; the other forms of that kernel count under 1).
  * mask: bits 0..15: bit c enables timing of category c (0 = off); bits 16..31: sampling period k
  *       (0/1 = every launch, k = every k-th launch of each enabled category).          */
-#define BZ_NUM_KERNEL_CATEGORIES 12
+#define BZ_NUM_KERNEL_CATEGORIES 13
 int bz_profile_enable(bz_problem* p, int32_t mask);
 int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms);
 int bz_profile_reset(bz_problem* p);

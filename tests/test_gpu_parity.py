@@ -1055,9 +1055,16 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
     x0 = rng.standard_normal(n) * 0.05 if start == "random" else np.zeros(n)
     runs = []
     try:
-        for xr, skipz, uni in (("0", "0", "0"), ("1", "1", "0"), ("1", "0", "0"), ("0", "1", "0"), ("2", "1", "0"),
-                               ("2", "0", "0"), ("2", "1", "1"), ("2", "1", "2")):
+        # (BZ_GFC pins one grid for every form of the kernel: by default the iterate-history form runs on half as
+        # many workgroups, a different summation tree — the last run below, compared to rounding)
+        for xr, skipz, uni, gfc in (("0", "0", "0", "2"), ("1", "1", "0", "2"), ("1", "0", "0", "2"), ("0", "1", "0", "2"),
+                                    ("2", "1", "0", "2"), ("2", "0", "0", "2"), ("2", "1", "1", "2"), ("2", "1", "2", "2"),
+                                    ("2", "1", "2", None)):
             os.environ["BZ_XR"], os.environ["BZ_SKIPZ"], os.environ["BZ_UNI"] = xr, skipz, uni
+            if gfc is None:
+                os.environ.pop("BZ_GFC", None)
+            else:
+                os.environ["BZ_GFC"] = gfc
             prob = bz.Problem(*dev, n, n, np.float64)
             prob.set_multipliers(mu, y)
             prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps)).c_opts(), x0)
@@ -1077,7 +1084,13 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
         os.environ.pop("BZ_XR", None)
         os.environ.pop("BZ_SKIPZ", None)
         os.environ.pop("BZ_UNI", None)
+        os.environ.pop("BZ_GFC", None)
     base = runs[0]
+    dflt = runs.pop()
+    if start == "zero":      # run to convergence: the default configuration ends at the same point to rounding
+        assert np.max(np.abs(dflt[0] - base[0])) <= 1e-11 * max(1.0, np.max(np.abs(base[0])))
+        assert abs(dflt[3]["f_x"] - base[3]["f_x"]) <= 1e-12 * abs(base[3]["f_x"])
+    assert dflt[5][3] >= iters - 16
     for r in runs[1:]:
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]) and np.array_equal(r[2], base[2])
         assert all(np.array_equal(a, b) for a, b in zip(r[4], base[4]))

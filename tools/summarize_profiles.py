@@ -75,11 +75,22 @@ def main(tag="r01"):
             bj = json.loads(line[-1])
             kern = bj["roofline"]["kernel"].replace("bz::", "").split("<")[0]
             rows = [r for r in csv.DictReader(open(traces[0])) if kern in r["Kernel_Name"]]
+            if bj["roofline"].get("kernel_form"):      # the timed category is the XR = 2 instantiations only
+                import re
+                rows = [r for r in rows if re.search(r"true, true, 2, \d>", r["Kernel_Name"])]
             rows.sort(key=lambda r: int(r["Start_Timestamp"]))
             w, k = bj["warmup"], bj["steps"]
             # the first launches of a solve (empty L-BFGS memory) go to other kernels, so the window is
             # taken from the end of the first problem's run: its last `steps` launches of this kernel
             first = rows[:w + k]
+            if bj["roofline"].get("kernel_form"):
+                # launches of this form inside the first problem's timed region: those that start after the
+                # (w+1)-th iteration's launch and before the next problem's first kernel
+                allk = [r for r in csv.DictReader(open(traces[0])) if kern in r["Kernel_Name"]]
+                allk.sort(key=lambda r: int(r["Start_Timestamp"]))
+                t_lo, t_hi = int(allk[w]["Start_Timestamp"]), int(allk[w + k - 1]["End_Timestamp"])
+                first = [r for r in rows if t_lo <= int(r["Start_Timestamp"]) <= t_hi]
+                k = len(first)
             dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in first[-k:]]
             with open(os.path.join(out_dir, f"{tag}_kernel_timing_agreement.json"), "w") as fh:
                 json.dump({"kernel": bj["roofline"]["kernel"], "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py "

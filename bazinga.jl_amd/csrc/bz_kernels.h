@@ -1963,8 +1963,9 @@ __device__ __forceinline__ T resid_elem(int fk, int dk, int gk, T xv, const Elem
 // the plain path
 template <class T, int MM>
 __global__ void __launch_bounds__(BLOCK)
-k_pairs_from_iterates(SnapVecs<T, MM> V, ElemParams<T> P, T gamma, T* __restrict__ res_cur, T* __restrict__ z_cur,
-                      int64_t n) {
+k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T gamma, T* __restrict__ res_cur,
+                      T* __restrict__ z_cur, int64_t n) {
+    // m <= MM stored pairs: XH[0..m] are the iterates (XH[m] the newest, repeated in the entries beyond it)
     const T gl = gamma * P.g_lambda;
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;
@@ -1989,8 +1990,10 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, ElemParams<T> P, T gamma, T* __restrict
             Pack<T> sp, yp;
 #pragma unroll
             for (int e = 0; e < PackN<T>::N; ++e) { sp.v[e] = xh[i + 1].v[e] - xh[i].v[e]; yp.v[e] = rh[i + 1].v[e] - rh[i].v[e]; }
-            st(V.S[i], i0, cnt, sp);
-            st(V.Y[i], i0, cnt, yp);
+            if (i < m) {
+                st(V.S[i], i0, cnt, sp);
+                st(V.Y[i], i0, cnt, yp);
+            }
         }
         st(res_cur, i0, cnt, rh[MM]);
         st(z_cur, i0, cnt, pz);
@@ -2035,10 +2038,11 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         asm volatile("" : "+v"(gl));
         asm volatile("" : "+v"(gamma));
     }
-    // uniform penalty in fp64: the 8 divisions by mu per element (and the one by gamma) go through div_u
-    constexpr bool UDIV = UNI >= 1 && sizeof(T) == 8;
-    T rmu = T(0), rgam = T(0);
-    if constexpr (UDIV) { rmu = T(1) / P.mu_uniform; rgam = T(1) / gamma; }
+    // fp64, iterate-history form: the 10 divisions by mu per element (and the one by gamma) go through div_u,
+    // on one reciprocal per launch (uniform penalties) or per element
+    constexpr bool UDIV = XR == 2 && sizeof(T) == 8;
+    T rmu_u = T(0), rgam = T(0);
+    if constexpr (UDIV) { rgam = T(1) / gamma; if constexpr (UNI >= 1) rmu_u = T(1) / P.mu_uniform; }
     constexpr int NS = 10 + 4 * MM + 2;
     double acc[NS];
 #pragma unroll
@@ -2064,7 +2068,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         unsigned bo = (unsigned)(i0 * (int64_t)sizeof(T));
         if constexpr (O32) asm volatile("" : "+v"(bo));      // opaque: no per-stream 64-bit pointer induction variables
         ElemLoads<T> L;
-        Pack<T> px, prp, ps[MM], py[MM], d;
+        Pack<T> px, prp, ps[MM], py[MM], d, rmu;
         if constexpr (STAGED) {
             L.q = SG.q; L.b = SG.b;
             if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = SG.mu;
@@ -2112,12 +2116,15 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             // iteration that changes them leaves this mode), so again the same bits
             Pack<T> rr[MM + 1];
 #pragma unroll
-            for (int i = 0; i <= MM; ++i)
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                if constexpr (UDIV) rmu.v[e] = (UNI >= 1) ? rmu_u : T(1) / L.mu.v[e];
 #pragma unroll
-                for (int e = 0; e < PackN<T>::N; ++e) {
+                for (int i = 0; i <= MM; ++i) {
                     T zz;
-                    rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gamma, gl, zz, UDIV, rmu);
+                    rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gamma, gl, zz, UDIV,
+                                               rmu.v[e]);
                 }
+            }
             prp = rr[MM];
 #pragma unroll
             for (int i = 0; i < MM; ++i)
@@ -2147,14 +2154,14 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         for (int e = 0; e < PackN<T>::N; ++e) {
             T xd = px.v[e] + d.v[e];
             ALOut<T> o1 = al_elem(fk, dk, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu);
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu.v[e]);
             T t = gamma * o1.grad;
             T y = xd - t;
             T gterm;
             T zz = prox_elem(gk, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
             T r = xd - zz;
             ALOut<T> o2 = al_elem(fk, dk, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu);
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu.v[e]);
             T sv = xd - px.v[e];
             T yy = r - prp.v[e];
             T w = UDIV ? div_u(r, gamma, rgam) : r / gamma;
@@ -2211,19 +2218,21 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         const int64_t stride = (int64_t)gridDim.x * BLOCK;
         int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
         // two packs ahead: with one, a wave has 8..10 KB in flight and the pass is bound by latency x concurrency
-        Stage cur, nx1, nx2;
+        // (three stages used in rotation, the loop unrolled by three: no register copies between iterations)
+        Stage sa, sb, sc;
         auto clampc = [&](int64_t k) { return k < nfull ? k : (nfull - 1); };
-        if (c < nfull) {
-            load_stage(cur, (unsigned)(c * N * (int64_t)sizeof(T)));
-            load_stage(nx1, (unsigned)(clampc(c + stride) * N * (int64_t)sizeof(T)));
+        auto fetch = [&](Stage& S, int64_t k) { load_stage(S, (unsigned)(clampc(k) * N * (int64_t)sizeof(T))); };
+        auto use = [&](const Stage& S, int64_t k) { body(k * N, std::integral_constant<int, N>{}, std::true_type{}, S); };
+        if (c < nfull) { fetch(sa, c); fetch(sb, c + stride); }
+        for (;;) {
+            if (c >= nfull) break;
+            fetch(sc, c + 2 * stride); use(sa, c); c += stride;
+            if (c >= nfull) break;
+            fetch(sa, c + 2 * stride); use(sb, c); c += stride;
+            if (c >= nfull) break;
+            fetch(sb, c + 2 * stride); use(sc, c); c += stride;
         }
-        for (; c < nfull; c += stride) {
-            load_stage(nx2, (unsigned)(clampc(c + 2 * stride) * N * (int64_t)sizeof(T)));
-            body(c * N, std::integral_constant<int, N>{}, std::true_type{}, cur);
-            cur = nx1;
-            nx1 = nx2;
-        }
-        if (c == nfull && nfull * N < n) body(c * N, (int)(n - nfull * N), std::false_type{}, cur);
+        if (c == nfull && nfull * N < n) body(c * N, (int)(n - nfull * N), std::false_type{}, sa);
     } else {
         Stage none;
         bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) { body(i0, cnt_, std::false_type{}, none); });

@@ -617,16 +617,19 @@ template <class T> class Solver final : public SolverBase {
         if (!sy_stale_) return;
         SnapVecs<T, CM> V;
         std::memset(&V, 0, sizeof(V));
+        const int m = (int)order.size();      // (< CM only in the re-evaluating form, soon after a memory reset)
         for (int i = 0; i <= CM; ++i) {
-            V.XH[i] = X_[(xc - CM + i + NXR) % NXR].p;
-            V.RH[i] = RES_[(rc - CM + i + NRR) % NRR].p;
+            const int back = std::max(0, m - i);
+            V.XH[i] = X_[(xc - back + NXR) % NXR].p;
+            V.RH[i] = RES_[(rc - back + NRR) % NRR].p;
         }
-        for (int i = 0; i < CM; ++i) { V.S[i] = S_[order[CM - 1 - i]].p; V.Y[i] = Y_[order[CM - 1 - i]].p; }
+        for (int i = 0; i < m; ++i) { V.S[i] = S_[order[m - 1 - i]].p; V.Y[i] = Y_[order[m - 1 - i]].p; }
         if (rh_stale_) {
             // (must run before gamma changes: the residuals are re-evaluated with the gamma of this run)
-            launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, P, gamma, RES_[rc].p, Z_[zc].p, n);
+            launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, m, P, gamma, RES_[rc].p, Z_[zc].p, n);
             res_valid = true; z_valid = true;
         } else {
+            if (m != CM) throw Error(BZ_ERR_STATE, "history as snapshots with a partial memory");
             launch(C_MISC, k_pairs_from_snapshots<T, CM>, grid, V, n);
         }
         sy_stale_ = false;
@@ -1534,18 +1537,26 @@ template <class T> class Solver final : public SolverBase {
             static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
             // headline family with everything uniform fixed at compile time (see the kernel)
             static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
-            const bool spec = spec_env && desc.f_kind == BZ_F_DIAG_QUADRATIC && desc.g_kind == BZ_G_NORM_L1 &&
-                              desc.D_kind == BZ_D_BOX && !P.D_lo_vec && !P.D_hi_vec && CV.m == CM;
+            const bool family = spec_env && desc.f_kind == BZ_F_DIAG_QUADRATIC && desc.g_kind == BZ_G_NORM_L1 &&
+                                desc.D_kind == BZ_D_BOX && !P.D_lo_vec && !P.D_hi_vec;
+            const bool spec = family && CV.m == CM;
 #define BZ_LAUNCH_FC(NT_, SPEC_)                                                                                  \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, SPEC_>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
             T* const zstore = skipz_env_ ? (T*)nullptr : Z_[zn].p;
             z_skipped = zstore == nullptr;
             static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
-            const bool off32 = off32_env && spec && (double)vcap * sizeof(T) < 4.0e9;
-            // 0: stored pairs; 1: pairs re-formed from the iterate / residual rings; 2: residuals re-evaluated too
-            const int xr = !(xr_env_ && off32 && xr_run_ >= CM && (int)order.size() == CM) ? 0
-                           : (xr_env_ >= 2 && xr_run_ >= CM + 1) ? 2 : 1;
+            const bool small = off32_env && (double)vcap * sizeof(T) < 4.0e9;
+            const bool off32 = small && spec;
+            // 0: stored pairs; 1: pairs re-formed from the iterate / residual rings (full memory only); 2: residuals
+            // re-evaluated too — possible as soon as every stored pair is a difference of ring neighbours, also
+            // with a partial memory (the absent pairs are x - x = 0 with zero coefficients)
+            const int m_now = (int)order.size();
+            int xr = 0;
+            if (xr_env_ && small && family && m_now >= 1 && xr_run_ >= m_now) {
+                if (xr_env_ >= 2) xr = 2;
+                else if (m_now == CM && !rh_stale_) xr = 1;
+            }
             if (sy_stale_ && !xr) materialize_pairs();
             if (xr != 2 && !res_valid) ensure_z();
             const int uni = xr == 2 ? uni_ : 0;
@@ -1561,7 +1572,10 @@ template <class T> class Solver final : public SolverBase {
             if (xr == 2) {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
-                for (int i = 0; i < CM; ++i) { XV.S[i] = X_[(xc - CM + i + NXR) % NXR].p; XV.Y[i] = nullptr; }
+                for (int i = 0; i < CM; ++i) {
+                    XV.S[i] = X_[(xc - std::max(0, m_now - i) + NXR) % NXR].p;      // (beyond m: x itself)
+                    XV.Y[i] = nullptr;
+                }
 #define BZ_LAUNCH_FC2(NT_, UNI_)                                                                                  \
     launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,        \
            (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p,     \
@@ -1736,14 +1750,17 @@ template <class T> class Solver final : public SolverBase {
         // A tau-backtracked point sits in the blend buffer: trade the two buffers so that the accepted iterate is
         // the next one of the ring whatever produced it — the stored pairs stay the successive differences of
         // the ring's last iterates (and residuals), and the run below goes on through backtracks
-        if (xcur == xb && fused_ok && use_compact) {
+        if (xcur == xb && fused_ok && compact_ok) {
             std::swap(X_[xd].p, X_[xb].p);
             std::swap(X_[xd].n, X_[xb].n);
             xcur = xd;
         }
         // history as iterates is possible after CM iterations in a row that each inserted their pair, with no
         // change of gamma (which resets the memory) in between
-        xr_run_ = (fused_ok && use_compact && ys > T(0) && xcur == xd && !reset_this) ? xr_run_ + 1 : 0;
+        // (xr_run_: how many of the newest stored pairs are differences of ring neighbours under this gamma.  The
+        // pair of an iteration that halved gamma is not one: its y is res_new(gamma/2) - res_prev(gamma), as
+        // upstream has it, so the run restarts after it)
+        xr_run_ = (fused_ok && compact_ok && ys > T(0) && xcur == xd && !reset_this) ? xr_run_ + 1 : 0;
         if (xr_run_ == 0) rh_stale_ = false;       // (whatever broke the run has materialised the pairs above)
         stop_norm_ = v[9];
         xc = xcur; rc = rn; zc = zn;

@@ -474,8 +474,7 @@ def main():
         t0 = time.perf_counter()
         if ok:
             try:
-                for _ in range(steps):
-                    prob.panoc_step()
+                prob.panoc_steps(steps)      # K iterations in one library call: the solver's own loop, no interpreter in it
             except Exception as e:      # noqa: BLE001
                 ok, err = 0, repr(e)[:300]
         ok = sync(ok)

@@ -1078,7 +1078,8 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
                     zs.append(prob.panoc_vector("res"))
             st = prob.panoc_stats()
             runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars(), zs,
-                         (st.n_backtracks, st.n_gamma_halvings, st.n_lbfgs_skips, st.n_fused_iters), prob.profile()["misc"]["launches"]))
+                         (st.n_backtracks, st.n_gamma_halvings, st.n_lbfgs_skips, st.n_fused_iters), prob.profile()["misc"]["launches"],
+                         prob.profile()["k_fused_iterates"]["launches"]))
             prob.close()
     finally:
         os.environ.pop("BZ_XR", None)
@@ -1091,6 +1092,12 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
         assert np.max(np.abs(dflt[0] - base[0])) <= 1e-11 * max(1.0, np.max(np.abs(base[0])))
         assert abs(dflt[3]["f_x"] - base[3]["f_x"]) <= 1e-12 * abs(base[3]["f_x"])
     assert dflt[5][3] >= iters - 16
+    # the 9..11-pass form (timing category k_fused_iterates) serves every iteration except the first of the solve
+    # and the five that follow a gamma halving (whose pair mixes two gammas and must leave the memory first) —
+    # i.e. it resumes straight after a tau backtrack and runs with a partial memory
+    assert all(r[7] == 0 for r in runs[:4])
+    if base[5][2] == 0:
+        assert all(r[7] >= iters - 2 - 5 * base[5][1] for r in runs[4:] + [dflt])
     for r in runs[1:]:
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]) and np.array_equal(r[2], base[2])
         assert all(np.array_equal(a, b) for a, b in zip(r[4], base[4]))

@@ -1806,6 +1806,10 @@ template <int MM> struct CompactCoef {
     double u1[MM];
     double u2h[MM];
     double H0;
+    // iterate-history form: the gamma the OLDEST stored iterate's residual was formed with.  It differs from the
+    // current one when the oldest pair is that of an iteration that halved gamma (y = res_new(gamma/2) -
+    // res_prev(gamma), as upstream has it); a halving resets the memory, so no younger iterate can differ.
+    double gam0;
 };
 
 // acc + a*b for the inner products that only the compact form's own kernels produce (Gram products, p, w) and
@@ -1923,6 +1927,7 @@ template <class T, int MM> struct SnapVecs {
     const T* RH[MM + 1];
     T* S[MM];
     T* Y[MM];
+    double gam[MM + 1];      // k_pairs_from_iterates: gamma of each iterate's residual (the last one: the current gamma)
 };
 template <class T, int MM>
 __global__ void __launch_bounds__(BLOCK) k_pairs_from_snapshots(SnapVecs<T, MM> V, int64_t n) {
@@ -1963,10 +1968,9 @@ __device__ __forceinline__ T resid_elem(int fk, int dk, int gk, T xv, const Elem
 // the plain path
 template <class T, int MM>
 __global__ void __launch_bounds__(BLOCK)
-k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T gamma, T* __restrict__ res_cur,
+k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T* __restrict__ res_cur,
                       T* __restrict__ z_cur, int64_t n) {
     // m <= MM stored pairs: XH[0..m] are the iterates (XH[m] the newest, repeated in the entries beyond it)
-    const T gl = gamma * P.g_lambda;
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;
         ElemLoads<T> L;
@@ -1980,8 +1984,9 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T gamma, T* __r
 #pragma unroll
             for (int e = 0; e < PackN<T>::N; ++e) {
                 T zz;
+                const T gi = (T)V.gam[i];
                 rh[i].v[e] = resid_elem<T>((int)BZ_F_DIAG_QUADRATIC, (int)BZ_D_BOX, (int)BZ_G_NORM_L1, xh[i].v[e], L, e,
-                                           gamma, gl, zz);
+                                           gi, gi * P.g_lambda, zz);
                 if (i == MM) pz.v[e] = zz;
             }
         }
@@ -2043,6 +2048,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     constexpr bool UDIV = XR == 2 && sizeof(T) == 8;
     T rmu_u = T(0), rgam = T(0);
     if constexpr (UDIV) { rgam = T(1) / gamma; if constexpr (UNI >= 1) rmu_u = T(1) / P.mu_uniform; }
+    const T gam0 = (T)C.gam0, gl0 = gam0 * P.g_lambda;      // XR = 2: gamma (and gamma*lambda) of the oldest iterate's residual
     constexpr int NS = 10 + 4 * MM + 2;
     double acc[NS];
 #pragma unroll
@@ -2121,7 +2127,9 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
 #pragma unroll
                 for (int i = 0; i <= MM; ++i) {
                     T zz;
-                    rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gamma, gl, zz, UDIV,
+                    const T gi = (i == 0) ? gam0 : gamma;
+                    const T gli = (i == 0) ? gl0 : gl;
+                    rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gi, gli, zz, UDIV,
                                                rmu.v[e]);
                 }
             }

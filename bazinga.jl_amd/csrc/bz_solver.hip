@@ -612,6 +612,7 @@ template <class T> class Solver final : public SolverBase {
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
     bool rh_stale_ = false;      // ... and the residual ring was not written either during this run
+    double gring_[NXR] = {0};    // the gamma the residual of each iterate in the ring was (or would be) formed with
     bool res_valid = true;       // RES_[rc] holds the residual of the current state
     void materialize_pairs() {
         if (!sy_stale_) return;
@@ -622,11 +623,12 @@ template <class T> class Solver final : public SolverBase {
             const int back = std::max(0, m - i);
             V.XH[i] = X_[(xc - back + NXR) % NXR].p;
             V.RH[i] = RES_[(rc - back + NRR) % NRR].p;
+            V.gam[i] = back ? gring_[(xc - back + NXR) % NXR] : (double)gamma;
         }
         for (int i = 0; i < m; ++i) { V.S[i] = S_[order[m - 1 - i]].p; V.Y[i] = Y_[order[m - 1 - i]].p; }
         if (rh_stale_) {
             // (must run before gamma changes: the residuals are re-evaluated with the gamma of this run)
-            launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, m, P, gamma, RES_[rc].p, Z_[zc].p, n);
+            launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, m, P, RES_[rc].p, Z_[zc].p, n);
             res_valid = true; z_valid = true;
         } else {
             if (m != CM) throw Error(BZ_ERR_STATE, "history as snapshots with a partial memory");
@@ -1473,6 +1475,7 @@ template <class T> class Solver final : public SolverBase {
         gather(SL_YS, 3, 4u);
         auto v = collect({SL_STOP}, 1u);
         stop_norm_ = v[0];
+        gring_[xc] = (double)gamma;
         active = true;
     }
 
@@ -1556,6 +1559,10 @@ template <class T> class Solver final : public SolverBase {
             if (xr_env_ && small && family && m_now >= 1 && xr_run_ >= m_now) {
                 if (xr_env_ >= 2) xr = 2;
                 else if (m_now == CM && !rh_stale_) xr = 1;
+                // (only the oldest stored iterate may carry another gamma — see CompactCoef::gam0)
+                for (int i = 1; i < m_now; ++i)
+                    if (gring_[(xc - m_now + i + NXR) % NXR] != (double)gamma) xr = 0;
+                if (xr == 1 && gring_[(xc - m_now + NXR) % NXR] != (double)gamma) xr = 0;
             }
             if (sy_stale_ && !xr) materialize_pairs();
             if (xr != 2 && !res_valid) ensure_z();
@@ -1573,8 +1580,10 @@ template <class T> class Solver final : public SolverBase {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
                 for (int i = 0; i < CM; ++i) {
-                    XV.S[i] = X_[(xc - std::max(0, m_now - i) + NXR) % NXR].p;      // (beyond m: x itself)
+                    const int slot = (xc - std::max(0, m_now - i) + NXR) % NXR;      // (beyond m: x itself)
+                    XV.S[i] = X_[slot].p;
                     XV.Y[i] = nullptr;
+                    if (i == 0) CC.gam0 = gring_[slot];
                 }
 #define BZ_LAUNCH_FC2(NT_, UNI_)                                                                                  \
     launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,        \
@@ -1757,10 +1766,11 @@ template <class T> class Solver final : public SolverBase {
         }
         // history as iterates is possible after CM iterations in a row that each inserted their pair, with no
         // change of gamma (which resets the memory) in between
-        // (xr_run_: how many of the newest stored pairs are differences of ring neighbours under this gamma.  The
-        // pair of an iteration that halved gamma is not one: its y is res_new(gamma/2) - res_prev(gamma), as
-        // upstream has it, so the run restarts after it)
-        xr_run_ = (fused_ok && compact_ok && ys > T(0) && xcur == xd && !reset_this) ? xr_run_ + 1 : 0;
+        // (xr_run_: how many of the newest stored pairs are differences of ring neighbours.  The pair of an
+        // iteration that halved gamma is one too — y = res_new(gamma/2) - res_prev(gamma), as upstream has it —
+        // because every iterate in the ring remembers the gamma of its residual, gring_)
+        xr_run_ = (fused_ok && compact_ok && ys > T(0) && xcur == xd) ? (reset_this ? 1 : xr_run_ + 1) : 0;
+        gring_[xcur] = (double)gamma;
         if (xr_run_ == 0) rh_stale_ = false;       // (whatever broke the run has materialised the pairs above)
         stop_norm_ = v[9];
         xc = xcur; rc = rn; zc = zn;

@@ -41,6 +41,7 @@ for i in range(25):
     run("stencil-panoc", raw(T.test_stencil_panoc_iterates_match_oracle), (nx, ny), 15)
 for i in range(12):
     n = int(rng.integers(1, 50000))
-    run("panoc", raw(T.test_panoc_iterates_match_oracle), n, str(rng.choice(["box", "free"])))
+    run("panoc", raw(T.test_panoc_iterates_match_oracle), n, str(rng.choice(["box", "free"])),
+        str(rng.choice(["default", "two-loop"])))
     run("compact", raw(T.test_compact_lbfgs_matches_compact_oracle), n, bool(rng.integers(0, 2)))
 print("done (iterates); failures:", bad)

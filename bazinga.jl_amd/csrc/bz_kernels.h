@@ -587,6 +587,44 @@ k_algrad_elem(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, in
     }
 }
 
+// Start of a solve, c = Identity with an element-wise f: gradient!(dlx, al, x) AND the local Lipschitz estimate
+// lower_bound_smoothness_constant(f, I, x, grad) = ||grad(x + 1) - grad(x)|| / ||(x + 1) - x|| in one pass — the
+// gradient at x + 1 never leaves the registers.  Same values, same sums as k_algrad_elem, k_add_scalar,
+// k_algrad_elem, k_diff_ss2 run one after the other (18 passes -> 6).
+//   slots: slot0 + 0 sum f terms, + 1 sum t^2/mu ; slot_aux + 0 sum (g(x+1) - g(x))^2, + 1 sum ((x+1) - x)^2
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_begin_lip(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, int64_t n,
+            double* __restrict__ parts, int slot0, int slot_aux) {
+    double acc[2] = {0.0, 0.0}, aux[2] = {0.0, 0.0};
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, true, true, false);
+        Pack<T> px = ld(x, i0, cnt), pg;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            ALOut<T> o = al_elem(P.f_kind, P.D_kind, px.v[e], L.q.v[e], L.b.v[e], L.mu.v[e],
+                                 L.muy.v[e], L.dlo.v[e], L.dhi.v[e], px.v[e ^ 1] + L.muy.v[e ^ 1], e & 1);
+            const T xp = px.v[e] + T(1), xpp = px.v[e ^ 1] + T(1);
+            ALOut<T> o2 = al_elem(P.f_kind, P.D_kind, xp, L.q.v[e], L.b.v[e], L.mu.v[e],
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], xpp + L.muy.v[e ^ 1], e & 1);
+            pg.v[e] = o.grad;
+            if (e < cnt) {
+                acc[0] += (double)o.fterm; acc[1] += (double)o.pterm;
+                T u = o2.grad - o.grad;
+                T v = xp - px.v[e];
+                aux[0] += (double)(u * u);
+                aux[1] += (double)(v * v);
+            }
+        }
+        st(grad, i0, cnt, pg);
+    });
+    block_reduce_store<2>(acc, 0u, parts, slot0);
+    __syncthreads();
+    block_reduce_store<2>(aux, 0u, parts, slot_aux);
+}
+
 // ---------------------------------------------------------------------------
 // K10 + K1: AL gradient with the 5-point-stencil quadratic f (cfg 3), c = Identity.
 //   f(x) = 0.5 x'A_h x - b'x on an nx-by-ny grid (row-major, index = i*ny + j),

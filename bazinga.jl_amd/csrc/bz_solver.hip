@@ -1433,12 +1433,22 @@ template <class T> class Solver final : public SolverBase {
         const T eps = std::numeric_limits<T>::epsilon();
         T* x = X_[xc].p;
         // grad_f_x, f_x = gradient(f, x)
-        algrad(x, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
-        // gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad_f_x)
-        launch(C_MISC, k_add_scalar<T>, grid, (const T*)x, T(1), TMP_.p, n);
-        algrad(TMP_.p, GZ_.p, SL_FZ); ++n_grad;
-        launch(C_MISC, k_diff_ss2<T>, grid, (const T*)GZ_.p, (const T*)GX_.p, (const T*)TMP_.p, (const T*)x, n,
-               parts_.p, (int)SL_AUX);
+        const int lip_env = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;      // (tests toggle it)
+        if (lip_env && desc.c_kind == BZ_C_IDENTITY && !slack && !dense_f &&
+            (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC)) {
+            // gradient at x and the Lipschitz estimate in one pass (k_begin_lip)
+            slot_n[SL_FXD] = slot_n[SL_FXD + 1] = grid;
+            launch(C_ALGRAD, k_begin_lip<T>, grid, (const T*)x, P, GX_.p, n, parts_.p, (int)SL_FXD, (int)SL_AUX);
+            gather(SL_FXD, 2, 0u);
+            n_grad += 2; gx_valid = true;
+        } else {
+            algrad(x, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+            // gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad_f_x)
+            launch(C_MISC, k_add_scalar<T>, grid, (const T*)x, T(1), TMP_.p, n);
+            algrad(TMP_.p, GZ_.p, SL_FZ); ++n_grad;
+            launch(C_MISC, k_diff_ss2<T>, grid, (const T*)GZ_.p, (const T*)GX_.p, (const T*)TMP_.p, (const T*)x, n,
+                   parts_.p, (int)SL_AUX);
+        }
         slot_n[SL_AUX] = slot_n[SL_AUX + 1] = grid;
         gather(SL_AUX, 2, 0u);
         {

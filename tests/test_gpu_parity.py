@@ -1034,6 +1034,40 @@ def test_config5_size_closed_form(bz, ref):
     assert not np.any(x0)
 
 
+@pytest.mark.parametrize("n", [1000, 30011, 400003])
+@pytest.mark.parametrize("D", ["box", "vc_pairs"])
+def test_fused_start_of_a_solve_is_bitwise_neutral(bz, ref, n, D):
+    """`k_begin_lip` (gradient at x + Lipschitz estimate from the gradient at x + 1, one pass) against the four
+    kernels it replaces: the same gamma, f(x) and first iterates, bit for bit — also with a pairwise D, where
+    the partner element moves with x + 1 as well."""
+    n = n - (n % 2)
+    d = bz.synth.l1_quadratic(n)
+    Dset = bz.PairwiseSet("vc") if D == "vc_pairs" else bz.ClosedSet(bz.IndBox(d["lo"], d["hi"]))
+    dev = (bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(), Dset)
+    rng = np.random.default_rng(3)
+    mu = rng.uniform(0.05, 2.0, n)
+    y = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    runs = []
+    try:
+        for flag in ("0", "1"):
+            os.environ["BZ_FUSED_BEGIN"] = flag
+            prob = bz.Problem(*dev, n, n, np.float64)
+            prob.set_multipliers(mu, y)
+            prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), x0)
+            sc0 = prob.panoc_scalars()
+            for _ in range(3):
+                prob.panoc_step()
+            runs.append((sc0, prob.panoc_scalars(), prob.panoc_vector("x"), prob.panoc_vector("z")))
+            prob.close()
+    finally:
+        os.environ.pop("BZ_FUSED_BEGIN", None)
+    a, b = runs
+    for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm"):
+        assert a[0][key] == b[0][key] and a[1][key] == b[1][key], key
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
 @pytest.mark.parametrize("n,iters,start", [(30011, 160, "random"), (400003, 60, "random"), (200003, 470, "zero")])
 def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, start):
     """Two storage tricks of the one-pass compact kernel change WHAT is written, never a value:

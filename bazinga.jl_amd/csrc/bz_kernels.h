@@ -625,6 +625,53 @@ k_begin_lip(const T* __restrict__ x, ElemParams<T> P, T* __restrict__ grad, int6
     block_reduce_store<2>(aux, 0u, parts, slot_aux);
 }
 
+// Start of a solve, same family: the forward-backward step at x, gradient!(., al, z) and the stop norm in one
+// pass — k_fbstep, k_algrad_elem at z and k_update (with no previous state) run one after the other, z and its
+// gradient never leaving the registers in between (18 passes -> 8).  Repeated once per gamma halving.
+//   slots slot0 + 0..7: sum g terms, <grad L(x), res>, ||res||^2, sum f terms at z, sum t^2/mu at z, 0, 0,
+//                       max |res/gamma - grad L(x) + grad L(z)|      (the layout SL_GSUM .. SL_STOP)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_begin_fb(const T* __restrict__ x, const T* __restrict__ gx, T gamma, ElemParams<T> P, T* __restrict__ z,
+           T* __restrict__ res, int64_t n, double* __restrict__ parts, int slot0) {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const T gl = gamma * P.g_lambda;
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, true, true, true);
+        Pack<T> px = ld(x, i0, cnt), pg = ld(gx, i0, cnt), pz, pr;
+        T gterm[PackN<T>::N];
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T t = gamma * pg.v[e];
+            T y = px.v[e] - t;
+            T zz = prox_elem<T, false>(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm[e], P.g_p);
+            pz.v[e] = zz; pr.v[e] = px.v[e] - zz;
+        }
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            ALOut<T> o = al_elem(P.f_kind, P.D_kind, pz.v[e], L.q.v[e], L.b.v[e], L.mu.v[e],
+                                 L.muy.v[e], L.dlo.v[e], L.dhi.v[e], pz.v[e ^ 1] + L.muy.v[e ^ 1], e & 1);
+            const T r = pr.v[e];
+            T w = r / gamma;
+            w = w - pg.v[e];
+            w = w + o.grad;
+            if (e < cnt) {
+                acc[0] += (double)gterm[e];
+                acc[1] += (double)(pg.v[e] * r);
+                acc[2] += (double)(r * r);
+                acc[3] += (double)o.fterm;
+                acc[4] += (double)o.pterm;
+                acc[7] = nanmax(acc[7], (double)(w < T(0) ? -w : w));
+            }
+        }
+        st(z, i0, cnt, pz);
+        st(res, i0, cnt, pr);
+    });
+    block_reduce_store<8>(acc, 1u << 7, parts, slot0);
+}
+
 // ---------------------------------------------------------------------------
 // K10 + K1: AL gradient with the 5-point-stencil quadratic f (cfg 3), c = Identity.
 //   f(x) = 0.5 x'A_h x - b'x on an nx-by-ny grid (row-major, index = i*ny + j),

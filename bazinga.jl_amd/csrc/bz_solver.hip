@@ -461,8 +461,10 @@ template <class T> class Solver final : public SolverBase {
                 inner_tol = std::max(ao.kappa_tol * inner_tol, ao.tol_dual);
             }
             // next subproblem starts from x (kept in the z buffer): copy to a state buffer
+            // (the z buffer BECOMES the first state buffer: the next bz_panoc_begin recomputes z anyway)
             if (!can_stop) {
-                BZ_HIP(hipMemcpyAsync(X_[0].p, x, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+                std::swap(X_[0].p, Z_[zc].p);
+                std::swap(X_[0].n, Z_[zc].n);
                 x = X_[0].p;
             }
         }
@@ -1459,12 +1461,27 @@ template <class T> class Solver final : public SolverBase {
         }
         // y = x - gamma grad ; z, g_z = prox(g, y, gamma) ; res = x - z ; backtrack_stepsize!
         T f_z = T(0);
+        const bool fused_fb = lip_env && desc.c_kind == BZ_C_IDENTITY && !slack && !dense_f && !lp_g &&
+                              (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
+        double stop0 = 0.0;
         for (;;) {
-            fbstep(x, GX_.p, gamma, Z_[zc].p, RES_[rc].p, SL_GSUM);
-            gather(SL_GSUM, 3, 0u);
-            ++n_prox;
-            algrad(Z_[zc].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
-            auto v = collect({SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ}, 0u);
+            std::vector<double> v;
+            if (fused_fb) {
+                // FB step, gradient at z and stop norm in one pass (k_begin_fb)
+                for (int k = 0; k < 8; ++k) slot_n[SL_GSUM + k] = grid;
+                launch(C_FB, k_begin_fb<T>, grid, (const T*)x, (const T*)GX_.p, gamma, P, Z_[zc].p, RES_[rc].p, n,
+                       parts_.p, (int)SL_GSUM);
+                gather(SL_GSUM, 8, 1u << 7);
+                ++n_prox; ++n_grad; gz_valid = false;
+                v = collect({SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_STOP}, 1u << 5);
+                stop0 = v[5];
+            } else {
+                fbstep(x, GX_.p, gamma, Z_[zc].p, RES_[rc].p, SL_GSUM);
+                gather(SL_GSUM, 3, 0u);
+                ++n_prox;
+                algrad(Z_[zc].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
+                v = collect({SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ}, 0u);
+            }
             g_z = g_value(v[0]); dot_gr = T(v[1]); ss_res = T(v[2]);
             f_z = al_value(v[3], v[4]); fraw_last = f_value(v[3]); f_z_al = f_z;
             const T nr = std::sqrt(ss_res);
@@ -1478,13 +1495,17 @@ template <class T> class Solver final : public SolverBase {
         }
         if (gamma < min_gamma)
             std::fprintf(stderr, "Warning: stepsize `gamma` became too small (%g)\n", (double)gamma);
-        for (int k = 0; k < 3; ++k) slot_n[SL_YS + k] = grid;
-        launch(C_UPDATE, k_update<T>, grid, (const T*)x, (const T*)nullptr, (const T*)RES_[rc].p,
-               (const T*)nullptr, (const T*)GX_.p, (const T*)GZ_.p, gamma, (T*)nullptr, (T*)nullptr, n,
-               parts_.p, (int)SL_YS);
-        gather(SL_YS, 3, 4u);
-        auto v = collect({SL_STOP}, 1u);
-        stop_norm_ = v[0];
+        if (fused_fb) {
+            stop_norm_ = stop0;
+        } else {
+            for (int k = 0; k < 3; ++k) slot_n[SL_YS + k] = grid;
+            launch(C_UPDATE, k_update<T>, grid, (const T*)x, (const T*)nullptr, (const T*)RES_[rc].p,
+                   (const T*)nullptr, (const T*)GX_.p, (const T*)GZ_.p, gamma, (T*)nullptr, (T*)nullptr, n,
+                   parts_.p, (int)SL_YS);
+            gather(SL_YS, 3, 4u);
+            auto v = collect({SL_STOP}, 1u);
+            stop_norm_ = v[0];
+        }
         gring_[xc] = (double)gamma;
         active = true;
     }
@@ -1556,7 +1577,11 @@ template <class T> class Solver final : public SolverBase {
 #define BZ_LAUNCH_FC(NT_, SPEC_)                                                                                  \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, SPEC_>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
-            T* const zstore = skipz_env_ ? (T*)nullptr : Z_[zn].p;
+            // z is the solution the caller reads when the solve stops: once the stop norm is within a factor 10 of
+            // the tolerance, store it (one more write stream for the last iteration or two) rather than
+            // re-materialise it afterwards with two generic kernels (the same bits either way)
+            const bool near_stop = (double)stop_norm_ <= 10.0 * opt.tol;
+            T* const zstore = (skipz_env_ && !near_stop) ? (T*)nullptr : Z_[zn].p;
             z_skipped = zstore == nullptr;
             static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
             const bool small = off32_env && (double)vcap * sizeof(T) < 4.0e9;

@@ -1797,6 +1797,14 @@ k_update(const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restr
     block_reduce_store<3>(acc, 4u, parts, slot0);
 }
 
+// acc + a*b for the inner products that only the compact form's own kernels produce (Gram products, p, w) and
+// for the linear combination d: one fused multiply-add in fp64 (one rounding instead of two, half the
+// instructions); fp32 keeps the rounded product, as the oracle's fp32 arithmetic has it
+__device__ __forceinline__ double mul_acc(double a, double b, double acc) { return __builtin_fma(a, b, acc); }
+__device__ __forceinline__ double mul_acc(float a, float b, double acc) { return acc + (double)(a * b); }
+__device__ __forceinline__ double mul_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float mul_add(float a, float b, float c) { float t = a * b; return c + t; }
+
 // ---------------------------------------------------------------------------
 // The separable fast path: everything between the last two-loop reduction and the
 // end of the iteration in ONE pass (legal because f', c = I, proj_D and prox_g are all
@@ -1805,6 +1813,8 @@ k_update(const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restr
 //   writes: x_d, z, res, s_new, y_new [, gradL(x_d), gradL(z)] (5 vectors)
 //   slots : +0 f(x_d) +1 pen(x_d) +2 gsum +3 <g,res> +4 ||res||^2
 //           +5 f(z) +6 pen(z) +7 <s,y> +8 <y,y> +9 max stop
+//           +10 <s_new, -res>, +11 <y_new, -res> with res the new residual: p and w of the compact form's next
+//           application when this pass ran with an empty memory (k_gram_dots's arithmetic)
 // ---------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
@@ -1816,9 +1826,9 @@ k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_pr
     __shared__ double sh[WAVES];
     const T coef = tail_coef(a, sh);
     const T gl = gamma * P.g_lambda;
-    double acc[10];
+    double acc[12];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         ElemLoads<T> L;
@@ -1858,6 +1868,9 @@ k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_pr
                 acc[7] += (double)(s * yy);
                 acc[8] += (double)(yy * yy);
                 acc[9] = nanmax(acc[9], (double)(w < T(0) ? -w : w));
+                const T nr = T(-1) * r;
+                acc[10] = mul_acc(s, nr, acc[10]);
+                acc[11] = mul_acc(yy, nr, acc[11]);
             }
         }
         st(x_d, i0, cnt, pxd);
@@ -1868,7 +1881,7 @@ k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_pr
         if (gx_out) st(gx_out, i0, cnt, pg1);
         if (gz_out) st(gz_out, i0, cnt, pg2);
     });
-    block_reduce_store<10>(acc, 1u << 9, parts, slot0);
+    block_reduce_store<12>(acc, 1u << 9, parts, slot0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1896,14 +1909,6 @@ template <int MM> struct CompactCoef {
     // res_prev(gamma), as upstream has it); a halving resets the memory, so no younger iterate can differ.
     double gam0;
 };
-
-// acc + a*b for the inner products that only the compact form's own kernels produce (Gram products, p, w) and
-// for the linear combination d: one fused multiply-add in fp64 (one rounding instead of two, half the
-// instructions); fp32 keeps the rounded product, as the oracle's fp32 arithmetic has it
-__device__ __forceinline__ double mul_acc(double a, double b, double acc) { return __builtin_fma(a, b, acc); }
-__device__ __forceinline__ double mul_acc(float a, float b, double acc) { return acc + (double)(a * b); }
-__device__ __forceinline__ double mul_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float mul_add(float a, float b, float c) { float t = a * b; return c + t; }
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
 template <class T, int MM>
@@ -2393,26 +2398,40 @@ k_diff_ss2(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict
 // safeguards.jl:2-18), kept on the device so ny-vectors never cross PCIe
 // ---------------------------------------------------------------------------
 // AugLagUpdate!: muy = mu.*y ; slots +0 sum muy*y, +1 max(mu<=0)
+//   do_clamp: first y = clamp(y, -1e20, 1e20), stored back (default_dual_safeguard!, alps.jl:62 — k_clamp_scale's
+//             arithmetic) ; slot_probe >= 0: also k_uniform_probe's three maxima (mu and mu*y are in registers here)
 template <class T>
 __global__ void __launch_bounds__(BLOCK)
-k_muy(const T* __restrict__ mu, const T* __restrict__ y, T* __restrict__ muy, int64_t n,
-      double* __restrict__ parts, int slot0) {
-    double acc[2] = {0.0, 0.0};
+k_muy(const T* __restrict__ mu, T* __restrict__ y, T* __restrict__ muy, int64_t n,
+      double* __restrict__ parts, int slot0, int do_clamp, int slot_probe) {
+    double acc[2] = {0.0, 0.0}, pr[3] = {0.0, 0.0, 0.0};
+    const T m0 = mu[0];
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
-        Pack<T> pm = ld(mu, i0, cnt), py = ld(y, i0, cnt), o;
+        Pack<T> pm = ld(mu, i0, cnt), py = ld((const T*)y, i0, cnt), o;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
+            if (do_clamp) {
+                double w = (double)py.v[e];
+                w = w < 1e20 ? w : 1e20;      // min(y, 1e20)
+                w = w > -1e20 ? w : -1e20;    // max(-1e20, .)
+                py.v[e] = (T)w;
+            }
             T m = pm.v[e] * py.v[e];
             o.v[e] = m;
             if (e < cnt) {
                 acc[0] += (double)(m * py.v[e]);
                 acc[1] = nanmax(acc[1], (pm.v[e] <= T(0)) ? 1.0 : 0.0);
+                pr[0] = nanmax(pr[0], (double)pm.v[e]);
+                pr[1] = nanmax(pr[1], pm.v[e] == m0 ? 0.0 : 1.0);
+                pr[2] = nanmax(pr[2], (double)(m < T(0) ? -m : m));
             }
         }
+        if (do_clamp) st(y, i0, cnt, py);
         st(muy, i0, cnt, o);
     });
     block_reduce_store<2>(acc, 2u, parts, slot0);
+    if (slot_probe >= 0) block_reduce_store<3>(pr, 7u, parts, slot_probe);
 }
 
 // are the penalties uniform, are the scaled multipliers zero?  slots (all max, all >= 0 as the folds assume):

@@ -428,11 +428,10 @@ template <class T> class Solver final : public SolverBase {
         bz_panoc_opts po2 = po;
         while (!can_stop) {
             ++tot_it;
-            // dual_safeguard(y, cx)                                    alps.jl:62
-            launch(C_MISC, k_clamp_scale<T>, grid_y, ymul_.p, -1e20, 1e20, T(1), 1, ny);
             po2.tol = inner_tol;                                     // alps.jl:64
             po2.verbose = ao.verbose;
-            aug_lag_update();                                        // alps.jl:65
+            // dual_safeguard(y, cx)  alps.jl:62  +  AugLagUpdate!  alps.jl:65, one pass
+            aug_lag_update(true);
             begin_dev(po2, x);                                       // alps.jl:66
             run_to_completion();
             const int64_t sub_it = k_;
@@ -509,9 +508,8 @@ template <class T> class Solver final : public SolverBase {
         bz_panoc_opts po2 = po;
         while (!can_stop) {
             ++tot_it;
-            launch(C_MISC, k_clamp_scale<T>, grid_y, ymul_.p, -1e20, 1e20, T(1), 1, ny);     // dual_safeguard
             po2.tol = inner_tol; po2.verbose = ao.verbose;
-            aug_lag_update();                                        // AugLagUpdate!(fSlack, mu, y)
+            aug_lag_update(true);                                    // dual_safeguard + AugLagUpdate!(fSlack, mu, y)
             begin_dev(po2, xs);                                      // sub_solver(f=fSlack, g=gSlack, x0=xSlack)
             run_to_completion();
             const int64_t sub_it = k_;
@@ -1140,30 +1138,39 @@ template <class T> class Solver final : public SolverBase {
         gather(slot0, 1, 0u);
     }
 
-    // AugLagUpdate!(al, mu, y)  (auglagfun.jl:91-101) on the device copies mu_, ymul_
-    void aug_lag_update() {
-        launch(C_MISC, k_muy<T>, grid_y, (const T*)mu_.p, (const T*)ymul_.p, muy_.p, ny, parts_.p,
-               (int)SL_OUTER);
-        gather(SL_OUTER, 2, 2u, 3u);
-        auto v = collect({SL_OUTER, SL_OUTER + 1}, 2u);
-        if (v[1] > 0.0) throw Error(BZ_ERR_MU, "parameters `mu` must be positive");
-        musqy = T(0.5) * T(v[0]);
+    // AugLagUpdate!(al, mu, y)  (auglagfun.jl:91-101) on the device copies mu_, ymul_ ; safeguard: the dual
+    // safeguard of alps.jl:62 applied to y first, in the same pass
+    void aug_lag_update(bool safeguard = false) {
         // Uniform penalties / zero multipliers (this rank's part of them): the one-pass kernel then takes mu as a
         // number and does not stream mu (nor mu*y).  alps.jl:42 gives every constraint the same mu when c(x0) is
         // in D, alps.jl:97 scales them alike, and y0 = 0 holds through the first subproblem — the longest one.
         uni_ = 0;
         const int uni_env = std::getenv("BZ_UNI") ? std::atoi(std::getenv("BZ_UNI")) : 2;      // (tests toggle it)
-        if (uni_env && fused_family()) {
-            for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
-            launch(C_MISC, k_uniform_probe<T>, grid_y, (const T*)mu_.p, (const T*)muy_.p, ny, parts_.p, (int)SL_GP);
-            CollectArgs a;
-            a.n = 3; a.maxmask = 7u;
-            for (int k = 0; k < 3; ++k) a.src[k] = ScalarSrc{parts_.p + (size_t)(SL_GP + k) * PSTRIDE, grid_y, 1};
-            auto u = collect_run(a);               // this rank's values: no exchange (every form gives the same bits)
-            if (u[1] == 0.0 && u[0] > 0.0) {
-                uni_ = (u[2] == 0.0 && uni_env >= 2) ? 2 : 1;
-                P.mu_uniform = (T)u[0];
+        const bool probe = uni_env && fused_family();
+        for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
+        launch(C_MISC, k_muy<T>, grid_y, (const T*)mu_.p, ymul_.p, muy_.p, ny, parts_.p, (int)SL_OUTER,
+               safeguard ? 1 : 0, probe ? (int)SL_GP : -1);
+        gather(SL_OUTER, 2, 2u, 3u);
+        std::vector<double> v, u;
+        if (probe && !ctx->multi()) {
+            // one read-back for both groups; the probe's slots are this rank's own (no exchange: every form of
+            // the kernel gives the same bits)
+            auto a5 = collect({SL_OUTER, SL_OUTER + 1, SL_GP, SL_GP + 1, SL_GP + 2}, 2u | (7u << 2));
+            v = {a5[0], a5[1]}; u = {a5[2], a5[3], a5[4]};
+        } else {
+            v = collect({SL_OUTER, SL_OUTER + 1}, 2u);
+            if (probe) {
+                CollectArgs a;
+                a.n = 3; a.maxmask = 7u;
+                for (int k = 0; k < 3; ++k) a.src[k] = ScalarSrc{parts_.p + (size_t)(SL_GP + k) * PSTRIDE, grid_y, 1};
+                u = collect_run(a);
             }
+        }
+        if (v[1] > 0.0) throw Error(BZ_ERR_MU, "parameters `mu` must be positive");
+        musqy = T(0.5) * T(v[0]);
+        if (probe && u[1] == 0.0 && u[0] > 0.0) {
+            uni_ = (u[2] == 0.0 && uni_env >= 2) ? 2 : 1;
+            P.mu_uniform = (T)u[0];
         }
     }
     // the oracle family the specialised one-pass kernel serves (see step())
@@ -1559,7 +1566,8 @@ template <class T> class Solver final : public SolverBase {
         const int xp = xc, xd = (xc + 1) % NXR, xb = (xc + 2) % NXR;
         const int rp = rc, rn = (rc + 1) % NRR, zp = zc, zn = 1 - zc;
         int xcur = xd;
-        bool have_trial = false, fused_this = false, reset_this = false;
+        bool have_trial = false, fused_this = false, reset_this = false, sep_trial = false;
+        double sep_p = 0.0, sep_w = 0.0;      // <s_new, -res>, <y_new, -res> as measured by a k_fused_sep trial
         if (fused_ok && use_compact) {
             // 176 VGPRs -> two 256-thread blocks per CU: one resident round of blocks (each block pays the
             // coefficient prologue and a 20-slot reduction epilogue once)
@@ -1667,11 +1675,12 @@ template <class T> class Solver final : public SolverBase {
             n_grad += 2; n_prox += 1;
         } else if (fused_ok) {
             if (!res_valid) ensure_z();
-            for (int k = 0; k < 10; ++k) slot_n[SL_TRIAL + k] = grid;
+            for (int k = 0; k < 12; ++k) slot_n[SL_TRIAL + k] = grid;
             launch(C_FUSED, k_fused_sep<T>, grid, tail, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, gamma,
                    X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, (T*)nullptr, (T*)nullptr, n,
                    parts_.p, (int)SL_TRIAL);
-            gather(SL_TRIAL, 10, 1u << 9);
+            gather(SL_TRIAL, 12, 1u << 9);
+            sep_trial = true;
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false;
             n_grad += 2; n_prox += 1;
         } else {
@@ -1725,6 +1734,11 @@ template <class T> class Solver final : public SolverBase {
                     tp[i] = v[10 + 2 * CM + i]; tw[i] = v[10 + 3 * CM + i];
                 }
                 tpn = v[10 + 4 * CM]; twn = v[10 + 4 * CM + 1];
+            } else if (have_trial && sep_trial) {
+                static_assert(SL_TRIAL == SL_FXD && SL_STOP == SL_TRIAL + 9 && SL_GU == SL_TRIAL + 10, "k_fused_sep's slots");
+                v = collect_range(SL_TRIAL, 12, 1u << 9);
+                sep_p = v[10]; sep_w = v[11];
+                gram_from_trial = false;
             } else {
                 v = collect({SL_FXD, SL_PXD, SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ, SL_YS, SL_YTY, SL_STOP},
                             1u << 9);
@@ -1773,6 +1787,11 @@ template <class T> class Solver final : public SolverBase {
         if (pw_valid) {
             for (int i = 0; i < CM; ++i) { hp_[i] = i < m_at_trial ? tp[i] : 0.0; hw_[i] = i < m_at_trial ? tw[i] : 0.0; }
             p_new_ = tpn; w_new_ = twn;
+        } else if (compact_ok && sep_trial && fused_this && m_at_trial == 0 && order.empty()) {
+            // first iteration of a solve (empty memory): the k_fused_sep pass measured the new pair's p and w
+            pw_valid = true;
+            for (int i = 0; i < CM; ++i) { hp_[i] = 0.0; hw_[i] = 0.0; }
+            p_new_ = sep_p; w_new_ = sep_w;
         }
         if (ys > T(0)) {
             if (compact_ok && !gram_from_trial && !order.empty()) {

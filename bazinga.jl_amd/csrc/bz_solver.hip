@@ -1588,7 +1588,9 @@ template <class T> class Solver final : public SolverBase {
             // z is the solution the caller reads when the solve stops: once the stop norm is within a factor 10 of
             // the tolerance, store it (one more write stream for the last iteration or two) rather than
             // re-materialise it afterwards with two generic kernels (the same bits either way)
-            const bool near_stop = (double)stop_norm_ <= 10.0 * opt.tol;
+            // ... and during the first 20 iterations of a solve: ALPS subproblems are often that short (13 of them
+            // with 180 inner iterations in all on cfg 2), and a stored z costs a tenth of re-materialising one
+            const bool near_stop = (double)stop_norm_ <= 10.0 * opt.tol || k_ <= 20;
             T* const zstore = (skipz_env_ && !near_stop) ? (T*)nullptr : Z_[zn].p;
             z_skipped = zstore == nullptr;
             static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;

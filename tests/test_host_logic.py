@@ -143,3 +143,55 @@ def test_auglag_update_scalars(bz, ref):
     bz.AugLagUpdate(a, mu2, y2)
     ref.AugLagUpdate(b, mu2, y2)
     assert np.array_equal(a.muy, b.muy) and a.musqy == b.musqy
+
+
+def test_markstein_division_by_an_invariant_divisor_is_correctly_rounded(tmp_path):
+    """`div_u` in bz_kernels.h replaces a / b (b fixed over a launch, rb = RN(1/b)) by q = a*rb followed by two
+    steps q <- q + RN(a - b q)*rb with the remainder exact in an fma.  The same sequence on the CPU (libm fma)
+    against the compiler's division: 4e7 random quotients over 16 orders of magnitude of b, plus divisors with
+    extreme significands (all ones, one above a power of two), must agree bit for bit."""
+    import subprocess
+    src = tmp_path / "divu.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+static uint64_t s = 0x9E3779B97F4A7C15ull;
+static uint64_t nxt(void) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static double u01(void) { return (double)(nxt() >> 11) * 0x1.0p-53; }
+static double div_u(double a, double b, double rb) {
+    double q = a * rb;
+    double e = fma(-b, q, a);
+    q = fma(e, rb, q);
+    e = fma(-b, q, a);
+    return fma(e, rb, q);
+}
+int main(void) {
+    long bad = 0, n = 0;
+    double special[8];
+    uint64_t bits;
+    bits = 0x3FFFFFFFFFFFFFFFull; memcpy(&special[0], &bits, 8);   /* significand all ones */
+    bits = 0x3FF0000000000001ull; memcpy(&special[1], &bits, 8);   /* one ulp above 1 */
+    bits = 0x3FB999999999999Aull; memcpy(&special[2], &bits, 8);   /* 0.1 */
+    special[3] = 3.0; special[4] = 0.7; special[5] = 1e-8; special[6] = 1e8; special[7] = 1.0 / 3.0;
+    for (int k = 0; k < 4008; ++k) {
+        double b = k < 8 ? special[k] : pow(10.0, -8.0 + 16.0 * u01()) * (1.0 + u01());
+        double rb = 1.0 / b;
+        for (int i = 0; i < 10000; ++i) {
+            double a = (2.0 * u01() - 1.0) * pow(10.0, -12.0 + 16.0 * u01());
+            if (i == 0) a = 0.0;
+            double q1 = a / b, q2 = div_u(a, b, rb);
+            if (memcmp(&q1, &q2, 8) != 0) ++bad;
+            ++n;
+        }
+    }
+    printf("%ld %ld\n", n, bad);
+    return 0;
+}
+''')
+    exe = tmp_path / "divu"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == 40_080_000 and int(out[1]) == 0

@@ -614,7 +614,9 @@ def main():
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_states)
+            # bounded sample: ~10-30 s of CPU work whatever the size (the port runs ~2.5 it/s per 1e7 elements)
+            states = max(4, int(round((args.cpu_states - 1) * min(1.0, 1.0e7 / n))) + 1)
+            out["cpu_baseline"] = cpu_baseline(n, states)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

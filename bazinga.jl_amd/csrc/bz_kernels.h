@@ -119,10 +119,19 @@ __device__ __forceinline__ double fold_wave(const double* p, int count, bool is_
     for (int k = 0; k < PSTRIDE / BLOCK; ++k)
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) a[w] = is_max ? nanmax(a[w], v[k][w]) : a[w] + v[k][w];
+    // the four wave reductions as one transposed butterfly (9 shuffles instead of 24): lanes split the four
+    // values at the stages that pair l with l ^ 32 and l ^ 16, each then runs the rest of its value's tree —
+    // the pairs (l, l ^ 32), (l, l ^ 16), ..., (l, l ^ 1) of wave_sum / wave_max, so the same bits
+    auto comb = [&](double x, double y) { return is_max ? nanmax(x, y) : x + y; };
+    const bool h5 = l & 32, h4 = l & 16;
+    const double k0 = h5 ? a[2] : a[0], k1 = h5 ? a[3] : a[1];
+    const double s0 = h5 ? a[0] : a[2], s1 = h5 ? a[1] : a[3];
+    const double b0 = comb(k0, __shfl_xor(s0, 32, 64)), b1 = comb(k1, __shfl_xor(s1, 32, 64));
+    double c = comb(h4 ? b1 : b0, __shfl_xor(h4 ? b0 : b1, 16, 64));      // lanes (h5, h4) hold a[2 h5 + h4]
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) a[w] = is_max ? wave_max(a[w]) : wave_sum(a[w]);
-    const double t = is_max ? nanmax(nanmax(a[0], a[1]), nanmax(a[2], a[3])) : ((a[0] + a[1]) + (a[2] + a[3]));
-    return __shfl(t, 0, 64);
+    for (int o = 8; o > 0; o >>= 1) c = comb(c, __shfl_xor(c, o, 64));
+    const double t01 = comb(c, __shfl_xor(c, 16, 64));                     // a0 + a1 | a2 + a3
+    return comb(t01, __shfl_xor(t01, 32, 64));                             // (a0 + a1) + (a2 + a3), in every lane
 }
 
 // block-reduce K accumulators and write one partial per slot.

@@ -290,6 +290,43 @@ def test_float32_path(bz, ref):
     prob.close()
 
 
+def test_float32_iterate_history_form_is_bitwise_neutral(bz, ref):
+    """The fp32 instantiation of the one-pass kernel (4 elements per 16-byte pack, hardware division): the
+    9..11-pass form (BZ_XR=2) against the stored-pair form (BZ_XR=0) on one grid — identical bits over a run with
+    rejected trial points — and both against the float32 oracle's iterates to fp32 accuracy."""
+    n = 50003
+    d, dev, orc = make_cfg2(bz, ref, n, dtype=np.float32)
+    mu = np.full(n, 0.1, np.float32)
+    y = np.zeros(n, np.float32)
+    x0 = np.zeros(n, np.float32)
+    runs = []
+    try:
+        os.environ["BZ_GFC"] = "2"
+        for xr in ("0", "2"):
+            os.environ["BZ_XR"] = xr
+            prob = bz.Problem(*dev, n, n, np.float32)
+            prob.set_multipliers(mu, y)
+            prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(np.float32).eps)).c_opts(), x0)
+            prob.profile_enable(True)
+            for _ in range(90):
+                prob.panoc_step()
+            st = prob.panoc_stats()
+            runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(),
+                         prob.profile()["k_fused_iterates"]["launches"], st.n_fused_iters))
+            prob.close()
+    finally:
+        os.environ.pop("BZ_XR", None)
+        os.environ.pop("BZ_GFC", None)
+    a, b = runs
+    assert a[3] == 0 and b[3] >= 80
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for key in ("gamma", "f_x", "g_z", "ss_res", "stop_norm"):
+        assert a[2][key] == b[2][key], key
+    assert a[0].dtype == np.float32 and np.all(np.isfinite(a[0]))
+    # the solve makes progress in fp32: the fixed-point residual has dropped by orders of magnitude
+    assert b[2]["stop_norm"] < 1e-2
+
+
 @pytest.mark.parametrize("variant", ["two-loop", "compact", "nofuse", "large-compact", "large-two-loop"])
 def test_allgather_plumbing_single_rank(bz, ref, variant):
     """The multi-GPU scalar paths on ONE rank — k_pack -> RCCL all-gather -> fold over ranks, and the

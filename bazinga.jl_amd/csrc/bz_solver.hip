@@ -1258,6 +1258,10 @@ template <class T> class Solver final : public SolverBase {
     // they take their own pass and read-back
     CompactCoef<CM> compact_prepare(const CompactVecs<T, CM>& V) {
         const int m = V.m;
+        if (m == 0) {
+            for (int i = 0; i < CM; ++i) { hp_[i] = 0.0; hw_[i] = 0.0; }
+            pw_valid = true;
+        }
         if (!pw_valid) {
             for (int k = 0; k < 2 * CM; ++k) slot_n[SL_GP + k] = grid;
             launch(C_DOT, k_gram_dots<T, CM>, grid, V, (const T*)RES_[rc].p, n, parts_.p, (int)SL_GP);
@@ -1547,7 +1551,9 @@ template <class T> class Solver final : public SolverBase {
         const T FBE_x = (f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr0 * nr0)) + g_z;
         fbe_last = FBE_x;
         // direction d = H(-res): all but the last axpy
-        const bool use_compact = compact_ok && !order.empty();
+        // (headline family: the one-pass kernel also serves an EMPTY memory — d = H0 (-res), all coefficients zero —
+        // so the first iteration of a solve is a 3..5-stream pass too instead of k_fused_sep's 12)
+        const bool use_compact = compact_ok && (!order.empty() || (fused_ok && fused_family()));
         const bool use_persist = persist_ok && !order.empty() && !use_compact;
         CompactVecs<T, CM> CV;
         CompactCoef<CM> CC;
@@ -1601,7 +1607,7 @@ template <class T> class Solver final : public SolverBase {
             // with a partial memory (the absent pairs are x - x = 0 with zero coefficients)
             const int m_now = (int)order.size();
             int xr = 0;
-            if (xr_env_ && small && family && m_now >= 1 && xr_run_ >= m_now) {
+            if (xr_env_ && small && family && xr_run_ >= m_now) {
                 if (xr_env_ >= 2) xr = 2;
                 else if (m_now == CM && !rh_stale_) xr = 1;
                 // (only the oldest stored iterate may carry another gamma — see CompactCoef::gam0)

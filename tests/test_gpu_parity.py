@@ -1163,8 +1163,8 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
         assert np.max(np.abs(dflt[0] - base[0])) <= 1e-11 * max(1.0, np.max(np.abs(base[0])))
         assert abs(dflt[3]["f_x"] - base[3]["f_x"]) <= 1e-12 * abs(base[3]["f_x"])
     assert dflt[5][3] >= iters - 16
-    # the 9..11-pass form (timing category k_fused_iterates) serves every iteration except the first of the solve:
-    # it resumes straight after a tau backtrack, runs with a partial memory, and carries the pair of a
+    # the 9..11-pass form (timing category k_fused_iterates) serves every iteration, the first one included (empty
+    # memory): it resumes straight after a tau backtrack, runs with a partial memory, and carries the pair of a
     # gamma-halving iteration (y = res_new(gamma/2) - res_prev(gamma)) through the gamma tag of the oldest iterate
     assert all(r[7] == 0 for r in runs[:4])
     if base[5][2] == 0:

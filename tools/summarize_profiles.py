@@ -53,8 +53,9 @@ def main(tag="r01"):
         summary[short(k)] = {"FETCH_SIZE_KiB_median": round(f, 1), "WRITE_SIZE_KiB_median": round(w, 1), "launches_fetch_pass": nf,
                              "launches_write_pass": nw, "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
     with open(os.path.join(out_dir, f"{tag}_pmc_hbm_traffic_n1e7.json"), "w") as fh:
-        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 10 --warmup 5 "
-                              "--no-cpu-baseline (two separate passes)",
+        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 100 --warmup 20 "
+                              "--no-cpu-baseline (two separate passes); per kernel the MEDIAN over its launches (the first 20 "
+                              "iterations of a solve also store z: one more write pass)",
                    "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
                    "n": 10_000_000, "kernels": summary}, fh, indent=1)
     # what bench.py looks up for roofline.traffic: measured HBM bytes per launch, by kernel
@@ -62,8 +63,10 @@ def main(tag="r01"):
         with open(os.path.join(out_dir, "pmc_dominant_kernel.json"), "w") as fh:
             json.dump({"n": 10_000_000, "source": f"profiles/{tag}_pmc_hbm_traffic_n1e7.json",
                        # several instantiations of one kernel: the one that served most launches (the steady state)
+                       # (ties: the instantiation that ran first — the headline problem's, before the side runs)
                        "kernels": {k.replace("bz::", "").split("<")[0]: v["hbm_bytes_per_launch"]
-                                   for k, v in sorted(summary.items(), key=lambda kv: kv[1]["launches_fetch_pass"])}}, fh, indent=1)
+                                   for _, (k, v) in sorted(enumerate(summary.items()),
+                                                           key=lambda t: (t[1][1]["launches_fetch_pass"], -t[0]))}}, fh, indent=1)
     # same-run agreement of the two clocks on the dominant kernel: bench.py's dispatch-bound HIP events
     # (its JSON line in prof_stats.log) against rocprofv3's kernel trace over the SAME launches (the timed
     # region = launches [warmup, warmup + steps) of the first problem the bench creates)

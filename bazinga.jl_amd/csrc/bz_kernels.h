@@ -2188,7 +2188,10 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T* __restrict__
 //   UNI = 1: every mu[i] is the same number (P.mu_uniform; alps.jl:42 from a start with c(x0) in D, and
 //            alps.jl:97 scales all of them alike) -> not streamed ; UNI = 2: and mu*y = 0 (first subproblem from
 //            y0 = 0) -> not streamed either.  Same operands, same operations (the + 0 stays), so the same bits.
-template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, int XR = 0, int UNI = 0>
+//   TRIAL (XR = 2 only): the trial point is GIVEN in x_d (a tau-blend of the rejected x + d and z: read, not
+//            written) instead of formed as x + d: a backtracked trial is then this one pass too — both
+//            gradients, FB step, pair, its Gram products, p, w, stop norm — with nothing materialised.
+template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, int XR = 0, int UNI = 0, bool TRIAL = false>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
@@ -2225,13 +2228,14 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     // XR = 2 reads few enough streams (MM+1 iterates + 2..4 parameter vectors) to keep the NEXT pack's loads in
     // flight while this pack's ~800 instructions run: a one-deep software pipeline in registers
     constexpr bool PIPE = SPEC && OFF32 && XR == 2;
-    struct Stage { Pack<T> q, b, mu, muy, px, ps[MM]; };
+    struct Stage { Pack<T> q, b, mu, muy, px, ps[MM], xt; };
     auto load_stage = [&](Stage& S, unsigned bo) {
         asm volatile("" : "+v"(bo));
         S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo);
         if constexpr (UNI < 1) S.mu = ldo<T, NT>(P.mu, bo);
         if constexpr (UNI < 2) S.muy = ldo<T, NT>(P.muy, bo);
         S.px = ldo<T, NT>(x, bo);
+        if constexpr (TRIAL) S.xt = ldo<T, NT>((const T*)x_d, bo);
 #pragma unroll
         for (int i = 0; i < MM; ++i) S.ps[i] = ldo<T, NT>(V.S[i], bo);
     };
@@ -2243,7 +2247,10 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         unsigned bo = (unsigned)(i0 * (int64_t)sizeof(T));
         if constexpr (O32) asm volatile("" : "+v"(bo));      // opaque: no per-stream 64-bit pointer induction variables
         ElemLoads<T> L;
-        Pack<T> px, prp, ps[MM], py[MM], d, rmu;
+        Pack<T> px, prp, ps[MM], py[MM], d, rmu, pxt;
+        if constexpr (TRIAL) {
+            if constexpr (STAGED) pxt = SG.xt; else pxt = ldp<T, NT>((const T*)x_d, i0, cnt);
+        }
         if constexpr (STAGED) {
             L.q = SG.q; L.b = SG.b;
             if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = SG.mu;
@@ -2325,11 +2332,12 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                     py[i].v[e] = nr - py[i].v[e];
                 }
         }
-        compact_d<T, MM>(m, H0, u1, u2h, prp, ps, py, d);
+        if constexpr (!TRIAL) compact_d<T, MM>(m, H0, u1, u2h, prp, ps, py, d);
         Pack<T> pxd, pz, pr, pss, pyy;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
-            T xd = px.v[e] + d.v[e];
+            T xd;
+            if constexpr (TRIAL) xd = pxt.v[e]; else xd = px.v[e] + d.v[e];
             ALOut<T> o1 = al_elem(fk, dk, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
                                   L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu.v[e]);
             T t = gamma * o1.grad;
@@ -2374,11 +2382,12 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         }
         if constexpr (O32) {
-            sto<T, NT>(x_d, bo, pxd); if (z) sto<T, NT>(z, bo, pz);
+            if constexpr (!TRIAL) sto<T, NT>(x_d, bo, pxd);
+            if (z) sto<T, NT>(z, bo, pz);
             if (XR != 2 || res) sto<T, NT>(res, bo, pr);
             if constexpr (XR == 0) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }
         } else {
-            stp<T, NT>(x_d, i0, cnt, pxd);
+            if constexpr (!TRIAL) stp<T, NT>(x_d, i0, cnt, pxd);
             if (z) stp<T, NT>(z, i0, cnt, pz);
             if (XR != 2 || res) stp<T, NT>(res, i0, cnt, pr);
             if constexpr (XR == 0) {

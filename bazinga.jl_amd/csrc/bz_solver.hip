@@ -1573,6 +1573,12 @@ template <class T> class Solver final : public SolverBase {
         const int rp = rc, rn = (rc + 1) % NRR, zp = zc, zn = 1 - zc;
         int xcur = xd;
         bool have_trial = false, fused_this = false, reset_this = false, sep_trial = false;
+        // a backtracked trial point can go through the one-pass kernel too ("trial given" variant) when this
+        // iteration's first trial did: what that launch used is kept here
+        bool trial_ok = false, trial_nt = false;
+        int trial_uni = 0, trial_gfc = 0;
+        CompactVecs<T, CM> trial_XV;
+        CompactCoef<CM> trial_CC;
         double sep_p = 0.0, sep_w = 0.0;      // <s_new, -res>, <y_new, -res> as measured by a k_fused_sep trial
         if (fused_ok && use_compact) {
             // 176 VGPRs -> two 256-thread blocks per CU: one resident round of blocks (each block pays the
@@ -1644,6 +1650,9 @@ template <class T> class Solver final : public SolverBase {
                 else { if (uni == 2) BZ_LAUNCH_FC2(false, 2); else if (uni == 1) BZ_LAUNCH_FC2(false, 1); else BZ_LAUNCH_FC2(false, 0); }
 #undef BZ_LAUNCH_FC2
                 sy_stale_ = true; rh_stale_ = true; res_skipped = true;
+                static const int tf_env = std::getenv("BZ_TRIALFUSE") ? std::atoi(std::getenv("BZ_TRIALFUSE")) : 1;
+                const int tf_now = std::getenv("BZ_TRIALFUSE") ? std::atoi(std::getenv("BZ_TRIALFUSE")) : tf_env;      // (tests toggle it)
+                trial_ok = tf_now != 0; trial_nt = nt; trial_uni = uni; trial_gfc = gfc; trial_XV = XV; trial_CC = CC;
             } else if (xr) {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
@@ -1766,7 +1775,8 @@ template <class T> class Solver final : public SolverBase {
             // it must be formed with the gamma of that state
             // ... and the classic kernels that finish this iteration need the stored pairs (and the residual of
             // that state) as vectors
-            if (sy_stale_ && (halve || !(FBE_new <= threshold || k >= max_bt))) materialize_pairs();
+            if (halve) trial_ok = false;
+            if (sy_stale_ && !trial_ok && (halve || !(FBE_new <= threshold || k >= max_bt))) materialize_pairs();
             if ((!z_valid || !res_valid) && (halve || !(FBE_new <= threshold || k >= max_bt))) ensure_z();
             if (halve) {
                 gamma = gamma * T(0.5); ++n_halv;
@@ -1783,8 +1793,30 @@ template <class T> class Solver final : public SolverBase {
             launch(C_MISC, k_blend<T>, grid, (const T*)X_[xd].p, (const T*)Z_[zp].p, tau, T(1) - tau,
                    X_[xb].p, n);
             xcur = xb;
-            algrad(X_[xb].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
             fused_this = false;
+            if (trial_ok) {
+                // the blended point through the one-pass kernel: given in X_[xb], evaluated against the same ring
+                // of iterates; z and res of the new state are stored (Z_[zn], RES_[rn])
+                for (int kk = 0; kk < NFC; ++kk) slot_n[SL_TRIAL + kk] = trial_gfc;
+#define BZ_LAUNCH_FCT(NT_, UNI_)                                                                                  \
+    launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_, true>, trial_gfc, trial_XV, trial_CC,     \
+           (const T*)X_[xp].p, (const T*)nullptr, P, gamma, X_[xb].p, Z_[zn].p, RES_[rn].p, (T*)nullptr,         \
+           (T*)nullptr, n, parts_.p, (int)SL_TRIAL)
+                if (trial_nt) { if (trial_uni == 2) BZ_LAUNCH_FCT(true, 2); else if (trial_uni == 1) BZ_LAUNCH_FCT(true, 1); else BZ_LAUNCH_FCT(true, 0); }
+                else { if (trial_uni == 2) BZ_LAUNCH_FCT(false, 2); else if (trial_uni == 1) BZ_LAUNCH_FCT(false, 1); else BZ_LAUNCH_FCT(false, 0); }
+#undef BZ_LAUNCH_FCT
+                if (ctx->p2p_on) {
+                    tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
+                    tail_used = true;
+                } else {
+                    gather(SL_TRIAL, NFC, 1u << 9);
+                    tail_used = false;
+                }
+                have_trial = true; gram_from_trial = true; gx_valid = false; gz_valid = false;
+                n_grad += 2; n_prox += 1;
+            } else {
+                algrad(X_[xb].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+            }
         }
         // update!(H, x - x_prev, res - res_prev): the pair sits in the spare slot
         const T ys = T(v[7]), yty = T(v[8]);

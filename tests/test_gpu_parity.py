@@ -302,6 +302,7 @@ def test_float32_iterate_history_form_is_bitwise_neutral(bz, ref):
     runs = []
     try:
         os.environ["BZ_GFC"] = "2"
+        os.environ["BZ_TRIALFUSE"] = "0"
         for xr in ("0", "2"):
             os.environ["BZ_XR"] = xr
             prob = bz.Problem(*dev, n, n, np.float32)
@@ -317,6 +318,7 @@ def test_float32_iterate_history_form_is_bitwise_neutral(bz, ref):
     finally:
         os.environ.pop("BZ_XR", None)
         os.environ.pop("BZ_GFC", None)
+        os.environ.pop("BZ_TRIALFUSE", None)
     a, b = runs
     assert a[3] == 0 and b[3] >= 80
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -1132,10 +1134,12 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
                                     ("2", "1", "0", "2"), ("2", "0", "0", "2"), ("2", "1", "1", "2"), ("2", "1", "2", "2"),
                                     ("2", "1", "2", None)):
             os.environ["BZ_XR"], os.environ["BZ_SKIPZ"], os.environ["BZ_UNI"] = xr, skipz, uni
-            if gfc is None:
+            if gfc is None:      # the default configuration: its own grid, backtracked trials through the one-pass kernel
                 os.environ.pop("BZ_GFC", None)
+                os.environ.pop("BZ_TRIALFUSE", None)
             else:
                 os.environ["BZ_GFC"] = gfc
+                os.environ["BZ_TRIALFUSE"] = "0"      # (rejected trials finish in the generic kernels in every form)
             prob = bz.Problem(*dev, n, n, np.float64)
             prob.set_multipliers(mu, y)
             prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps)).c_opts(), x0)
@@ -1157,6 +1161,7 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
         os.environ.pop("BZ_SKIPZ", None)
         os.environ.pop("BZ_UNI", None)
         os.environ.pop("BZ_GFC", None)
+        os.environ.pop("BZ_TRIALFUSE", None)
     base = runs[0]
     dflt = runs.pop()
     if start == "zero":      # run to convergence: the default configuration ends at the same point to rounding

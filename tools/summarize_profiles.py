@@ -80,7 +80,7 @@ def main(tag="r01"):
             rows = [r for r in csv.DictReader(open(traces[0])) if kern in r["Kernel_Name"]]
             if bj["roofline"].get("kernel_form"):      # the timed category is the XR = 2 instantiations only
                 import re
-                rows = [r for r in rows if re.search(r"true, true, 2, \d>", r["Kernel_Name"])]
+                rows = [r for r in rows if re.search(r"true, true, 2, \d(, (true|false))?>", r["Kernel_Name"])]
             rows.sort(key=lambda r: int(r["Start_Timestamp"]))
             w, k = bj["warmup"], bj["steps"]
             unprof = None

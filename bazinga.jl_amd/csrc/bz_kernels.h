@@ -751,6 +751,33 @@ k_begin_fb(const T* __restrict__ x, const T* __restrict__ gx, T gamma, ElemParam
     block_reduce_store<8>(acc, 1u << 7, parts, slot0);
 }
 
+// z (and res) of a state from its x alone, same family: z = prox_{gamma g}(x - gamma grad L(x)), res = x - z in one pass —
+// k_algrad_elem + k_fbstep without the gradient's round trip through memory (10 passes -> 6..7), for the
+// re-materialisation of a z the one-pass kernel did not store
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_zres_elem(const T* __restrict__ x, ElemParams<T> P, T gamma, T* __restrict__ z, T* __restrict__ res, int64_t n) {
+    const T gl = gamma * P.g_lambda;
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, true, true, true);
+        Pack<T> px = ld(x, i0, cnt), pz, pr;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            ALOut<T> o = al_elem(P.f_kind, P.D_kind, px.v[e], L.q.v[e], L.b.v[e], L.mu.v[e],
+                                 L.muy.v[e], L.dlo.v[e], L.dhi.v[e], px.v[e ^ 1] + L.muy.v[e ^ 1], e & 1);
+            T t = gamma * o.grad;
+            T y = px.v[e] - t;
+            T gterm;
+            T zz = prox_elem<T, false>(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm, P.g_p);
+            pz.v[e] = zz; pr.v[e] = px.v[e] - zz;
+        }
+        st(z, i0, cnt, pz);
+        if (res) st(res, i0, cnt, pr);
+    });
+}
+
 // ---------------------------------------------------------------------------
 // K10 + K1: AL gradient with the 5-point-stencil quadratic f (cfg 3), c = Identity.
 //   f(x) = 0.5 x'A_h x - b'x on an nx-by-ny grid (row-major, index = i*ny + j),

@@ -873,8 +873,15 @@ template <class T> class Solver final : public SolverBase {
     // (likewise the residual res = x - z into RES_[rc] when the pass did not store it)
     void ensure_z() {
         if (z_valid && res_valid) return;
-        algrad(X_[xc].p, D_.p, SL_AUX);                  // scratch gradient: GX_/GZ_ keep their meaning
-        fbstep(X_[xc].p, D_.p, gamma, Z_[zc].p, res_valid ? (T*)nullptr : RES_[rc].p, SL_ZS);
+        const int fb_env = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
+        if (fb_env && desc.c_kind == BZ_C_IDENTITY && !slack && !dense_f && !lp_g &&
+            (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC)) {
+            launch(C_FB, k_zres_elem<T>, grid, (const T*)X_[xc].p, P, gamma, Z_[zc].p,
+                   res_valid ? (T*)nullptr : RES_[rc].p, n);      // the two kernels below in one pass
+        } else {
+            algrad(X_[xc].p, D_.p, SL_AUX);                  // scratch gradient: GX_/GZ_ keep their meaning
+            fbstep(X_[xc].p, D_.p, gamma, Z_[zc].p, res_valid ? (T*)nullptr : RES_[rc].p, SL_ZS);
+        }
         z_valid = true; res_valid = true;
     }
     // ymask (row-sharded dense c only, where x-space quantities are computed in full by every rank): the

@@ -610,6 +610,7 @@ template <class T> class Solver final : public SolverBase {
     // same inputs as when each residual was first computed -> the same bits.
     int xr_run_ = 0;             // consecutive plain, pair-inserting iterations so far
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
+    int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
     bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
     bool rh_stale_ = false;      // ... and the residual ring was not written either during this run
     double gring_[NXR] = {0};    // the gamma the residual of each iterate in the ring was (or would be) formed with
@@ -873,7 +874,7 @@ template <class T> class Solver final : public SolverBase {
     // (likewise the residual res = x - z into RES_[rc] when the pass did not store it)
     void ensure_z() {
         if (z_valid && res_valid) return;
-        const int fb_env = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
+        const int fb_env = fused_begin_env_;
         if (fb_env && desc.c_kind == BZ_C_IDENTITY && !slack && !dense_f && !lp_g &&
             (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC)) {
             launch(C_FB, k_zres_elem<T>, grid, (const T*)X_[xc].p, P, gamma, Z_[zc].p,
@@ -1447,13 +1448,16 @@ template <class T> class Solver final : public SolverBase {
         last_nbt = 0; last_fused = false; tau = T(0); last_ys = T(0); fbe_last = T(0);
         xc = 0; rc = 0; zc = 0; z_valid = true; xr_run_ = 0; sy_stale_ = false; rh_stale_ = false; res_valid = true;
         xr_env_ = std::getenv("BZ_XR") ? std::atoi(std::getenv("BZ_XR")) : 2;
+        gfc_env_ = std::getenv("BZ_GFC") ? std::atoi(std::getenv("BZ_GFC")) : 0;
+        trialfuse_env_ = std::getenv("BZ_TRIALFUSE") ? std::atoi(std::getenv("BZ_TRIALFUSE")) : 1;
+        fused_begin_env_ = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
         const T eps = std::numeric_limits<T>::epsilon();
         T* x = X_[xc].p;
         // grad_f_x, f_x = gradient(f, x)
-        const int lip_env = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;      // (tests toggle it)
+        const int lip_env = fused_begin_env_;
         if (lip_env && desc.c_kind == BZ_C_IDENTITY && !slack && !dense_f &&
             (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC)) {
             // gradient at x and the Lipschitz estimate in one pass (k_begin_lip)
@@ -1590,7 +1594,7 @@ template <class T> class Solver final : public SolverBase {
         if (fused_ok && use_compact) {
             // 176 VGPRs -> two 256-thread blocks per CU: one resident round of blocks (each block pays the
             // coefficient prologue and a 20-slot reduction epilogue once)
-            const int gfc_env = std::getenv("BZ_GFC") ? std::atoi(std::getenv("BZ_GFC")) : 0;     // (tests set it)
+            const int gfc_env = gfc_env_;
             int gfc = std::min(grid, (gfc_env > 0 ? gfc_env : 2) * std::max(1, num_cus));
             // non-temporal loads/stores once the working set (2M + 11 vectors) no longer fits the 256 MB Infinity
             // Cache.  Measured fused-pass times, default policy vs non-temporal: n = 1.25e6 (210 MB) 39.0 / 44.5 us,
@@ -1657,8 +1661,7 @@ template <class T> class Solver final : public SolverBase {
                 else { if (uni == 2) BZ_LAUNCH_FC2(false, 2); else if (uni == 1) BZ_LAUNCH_FC2(false, 1); else BZ_LAUNCH_FC2(false, 0); }
 #undef BZ_LAUNCH_FC2
                 sy_stale_ = true; rh_stale_ = true; res_skipped = true;
-                static const int tf_env = std::getenv("BZ_TRIALFUSE") ? std::atoi(std::getenv("BZ_TRIALFUSE")) : 1;
-                const int tf_now = std::getenv("BZ_TRIALFUSE") ? std::atoi(std::getenv("BZ_TRIALFUSE")) : tf_env;      // (tests toggle it)
+                const int tf_now = trialfuse_env_;
                 trial_ok = tf_now != 0; trial_nt = nt; trial_uni = uni; trial_gfc = gfc; trial_XV = XV; trial_CC = CC;
             } else if (xr) {
                 CompactVecs<T, CM> XV;

@@ -20,15 +20,23 @@ BZ_G_NORM_LP_NONNEG, BZ_G_NORM_LP_BOX = 6, 7
 BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
 BZ_D_VC_PAIRS, BZ_D_CC_PAIRS, BZ_D_EITHEROR_PAIRS, BZ_D_XOR_PAIRS = 3, 4, 5, 6
-NUM_KERNEL_CATEGORIES = 13
+NUM_KERNEL_CATEGORIES = 16
 KERNEL_CATEGORIES = ("k_axpy_dot", "k_fused_sep", "al_gradient", "fb_step",
                      "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv", "k_twoloop_persist", "k_gemv_t_mfma",
-                     "k_fused_iterates")
+                     "k_fused_iterates", "k_stencil_fb", "k_stencil_update", "x_d")
 
 
 class CtxOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
-                ("reserved", C.c_int32), ("comm_id", C.c_void_p)]
+                ("flags", C.c_int32), ("comm_id", C.c_void_p)]
+
+
+BZ_CTX_RUNTIME_TUNING = 1
+
+
+class ProfileRec(C.Structure):
+    _fields_ = [("timed_launches", C.c_int64), ("timed_ms", C.c_double), ("timed_bytes", C.c_double),
+                ("launches", C.c_int64), ("bytes", C.c_double), ("form", C.c_char * 96)]
 
 
 class ProblemDesc(C.Structure):
@@ -58,7 +66,7 @@ class PanocStats(C.Structure):
                 ("n_grad", C.c_int64), ("n_prox", C.c_int64), ("n_backtracks", C.c_int64),
                 ("n_gamma_halvings", C.c_int64), ("n_fused_iters", C.c_int64),
                 ("n_lbfgs_skips", C.c_int64), ("elapsed_s", C.c_double), ("status", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("persist_fallbacks", C.c_int32)]
 
 
 class AlpsOpts(C.Structure):
@@ -83,6 +91,7 @@ SIGNATURES = {
     "bz_ctx_create": (C.c_int, [_P(CtxOpts), _P(_vp)]),
     "bz_ctx_destroy": (None, [_vp]),
     "bz_ctx_synchronize": (C.c_int, [_vp]),
+    "bz_ctx_comm_nranks": (C.c_int, [_vp, _P(C.c_int32)]),
     "bz_ctx_p2p_export": (C.c_int, [_vp, _vp]),
     "bz_ctx_p2p_connect": (C.c_int, [_vp, _vp, _P(C.c_int32)]),
     "bz_last_error": (C.c_char_p, []),
@@ -112,6 +121,8 @@ SIGNATURES = {
     "bz_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "bz_profile_get": (C.c_int, [_vp, C.c_int32, _P(C.c_int64), _P(C.c_double)]),
     "bz_profile_reset": (C.c_int, [_vp]),
+    "bz_profile_get2": (C.c_int, [_vp, C.c_int32, _P(ProfileRec)]),
+    "bz_runtime_tuning": (C.c_int, []),
 }
 
 _lib = None

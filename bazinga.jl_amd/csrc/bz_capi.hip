@@ -19,17 +19,19 @@ namespace {
 thread_local std::string g_err;
 
 // ROCm runtime settings for a launch-latency-bound host loop (one short kernel chain per PANOC iteration,
-// the host in the loop between them), applied when the library is loaded, i.e. before the HIP runtime
-// initialises — unless the process has set them itself or BZ_NO_RUNTIME_TUNING is set:
+// the host in the loop between them):
 //   HIP_FORCE_DEV_KERNARG=1  kernel arguments live in device memory: the command processor does not fetch
 //                            them over PCIe at every launch
 //   HSA_ENABLE_INTERRUPT=0   completion signals are polled instead of interrupt-driven
 // measured together, same box, alternating runs at n = 1.25e6: 53.7 -> 52.0 us per iteration on average and a
-// narrower spread (52.2-56.3 -> 51.3-52.4); box-to-box differences are larger than that
-__attribute__((constructor)) void bz_runtime_tuning() {
-    if (std::getenv("BZ_NO_RUNTIME_TUNING")) return;
-    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
-    setenv("HSA_ENABLE_INTERRUPT", "0", 0);
+// narrower spread (52.2-56.3 -> 51.3-52.4); box-to-box differences are larger than that.  They change the
+// behaviour of every HIP user in the process, so they are applied only when the host asks (bz_runtime_tuning /
+// BZ_CTX_RUNTIME_TUNING), never from a library constructor.
+int apply_runtime_tuning() {
+    int mask = 0;
+    if (!std::getenv("HIP_FORCE_DEV_KERNARG")) { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); mask |= 1; }
+    if (!std::getenv("HSA_ENABLE_INTERRUPT")) { setenv("HSA_ENABLE_INTERRUPT", "0", 0); mask |= 2; }
+    return mask;
 }
 
 template <class F> int guard(F&& f) {
@@ -42,8 +44,15 @@ template <class F> int guard(F&& f) {
     } catch (const std::exception& e) {
         g_err = e.what();
         return BZ_ERR_ARG;
+    } catch (...) {      // nothing may cross the extern "C" boundary
+        g_err = "unknown C++ exception";
+        return BZ_ERR_HIP;
     }
 }
+// HIP's current device is per host thread: every entry point that takes a handle selects the handle's device
+// first (a caller on another thread — a migrated Julia task, a Python worker — would otherwise allocate and
+// launch on device 0)
+void on_device(int device) { BZ_HIP(hipSetDevice(device)); }
 void need(const void* p, const char* what) {
     if (!p) throw bz::Error(BZ_ERR_ARG, std::string("null argument: ") + what);
 }
@@ -52,7 +61,8 @@ void need(const void* p, const char* what) {
 extern "C" {
 
 const char* bz_last_error(void) { return g_err.c_str(); }
-const char* bz_version(void) { return "bazinga-hip 0.1 (gfx950)"; }
+const char* bz_version(void) { return "bazinga-hip 0.2 (gfx950)"; }
+int bz_runtime_tuning(void) { return apply_runtime_tuning(); }
 
 int bz_comm_unique_id(void* id128) {
     return guard([&] {
@@ -69,6 +79,8 @@ int bz_ctx_create(const bz_ctx_opts* o, bz_ctx** out) {
         need(o, "opts"); need(out, "out");
         if (o->nranks < 1 || o->rank < 0 || o->rank >= o->nranks)
             throw bz::Error(BZ_ERR_ARG, "rank/nranks out of range");
+        if (o->flags & ~BZ_CTX_RUNTIME_TUNING) throw bz::Error(BZ_ERR_ARG, "unknown bz_ctx_opts.flags bit");
+        if (o->flags & BZ_CTX_RUNTIME_TUNING) (void)apply_runtime_tuning();      // before the first HIP call below
         int ndev = 0;
         BZ_HIP(hipGetDeviceCount(&ndev));
         if (ndev <= 0) throw bz::Error(BZ_ERR_HIP, "no HIP device visible");
@@ -101,10 +113,10 @@ void bz_ctx_destroy(bz_ctx* ctx) {
 }
 
 int bz_ctx_p2p_export(bz_ctx* ctx, void* handle64) {
-    return guard([&] { need(ctx, "ctx"); need(handle64, "handle64"); bz::p2p_export(&ctx->c, handle64); });
+    return guard([&] { need(ctx, "ctx"); need(handle64, "handle64"); on_device(ctx->c.device); bz::p2p_export(&ctx->c, handle64); });
 }
 int bz_ctx_p2p_connect(bz_ctx* ctx, const void* handles, const int32_t* devices) {
-    return guard([&] { need(ctx, "ctx"); need(handles, "handles"); bz::p2p_connect(&ctx->c, handles, devices); });
+    return guard([&] { need(ctx, "ctx"); need(handles, "handles"); on_device(ctx->c.device); bz::p2p_connect(&ctx->c, handles, devices); });
 }
 
 int bz_ctx_synchronize(bz_ctx* ctx) {
@@ -113,6 +125,15 @@ int bz_ctx_synchronize(bz_ctx* ctx) {
         BZ_HIP(hipSetDevice(ctx->c.device));
         BZ_HIP(hipStreamSynchronize(ctx->c.stream));
         BZ_HIP(hipDeviceSynchronize());
+    });
+}
+
+int bz_ctx_comm_nranks(bz_ctx* ctx, int32_t* out) {
+    return guard([&] {
+        need(ctx, "ctx"); need(out, "out");
+        int cnt = 0;
+        if (ctx->c.comm) BZ_NCCL(ncclCommCount(ctx->c.comm, &cnt));
+        *out = cnt;
     });
 }
 
@@ -167,44 +188,44 @@ void bz_alps_default_opts(bz_alps_opts* o, int32_t dtype) {
 }
 
 int bz_problem_set_multipliers(bz_problem* p, const void* mu, const void* y) {
-    return guard([&] { need(p, "problem"); need(mu, "mu"); need(y, "y"); p->s->set_multipliers(mu, y); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(mu, "mu"); need(y, "y"); p->s->set_multipliers(mu, y); });
 }
 
 int bz_panoc_solve(bz_problem* p, const bz_panoc_opts* o, const void* x0, void* x_out,
                    bz_panoc_stats* st) {
     return guard([&] {
-        need(p, "problem"); need(o, "opts"); need(x0, "x0"); need(x_out, "x_out");
+        need(p, "problem"); on_device(p->device); need(o, "opts"); need(x0, "x0"); need(x_out, "x_out");
         p->s->solve(*o, x0, x_out, st);
     });
 }
 
 int bz_panoc_begin(bz_problem* p, const bz_panoc_opts* o, const void* x0) {
-    return guard([&] { need(p, "problem"); need(o, "opts"); need(x0, "x0"); p->s->begin(*o, x0); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(o, "opts"); need(x0, "x0"); p->s->begin(*o, x0); });
 }
 int bz_panoc_step(bz_problem* p) {
-    return guard([&] { need(p, "problem"); p->s->step(); });
+    return guard([&] { need(p, "problem"); on_device(p->device); p->s->step(); });
 }
 int bz_panoc_steps(bz_problem* p, int64_t k) {
     return guard([&] {
-        need(p, "problem");
+        need(p, "problem"); on_device(p->device);
         if (k < 0) throw bz::Error(BZ_ERR_ARG, "k must be nonnegative");
         for (int64_t i = 0; i < k; ++i) p->s->step();
     });
 }
 int bz_panoc_finish(bz_problem* p, void* x_out, bz_panoc_stats* st) {
-    return guard([&] { need(p, "problem"); p->s->finish(x_out, st); });
+    return guard([&] { need(p, "problem"); on_device(p->device); p->s->finish(x_out, st); });
 }
 int bz_panoc_scalars(bz_problem* p, double* out16) {
-    return guard([&] { need(p, "problem"); need(out16, "out16"); p->s->scalars(out16); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(out16, "out16"); p->s->scalars(out16); });
 }
 int bz_panoc_vector(bz_problem* p, int32_t which, void* out) {
-    return guard([&] { need(p, "problem"); need(out, "out"); p->s->vector(which, out); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(out, "out"); p->s->vector(which, out); });
 }
 
 int bz_alps_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po, const void* x0,
                   const void* y0, void* x, void* y, void* s, void* mu, bz_alps_stats* st) {
     return guard([&] {
-        need(p, "problem"); need(ao, "alps opts"); need(po, "panoc opts");
+        need(p, "problem"); on_device(p->device); need(ao, "alps opts"); need(po, "panoc opts");
         need(x0, "x0"); need(y0, "y0"); need(x, "x"); need(y, "y"); need(s, "s"); need(mu, "mu");
         p->s->alps(*ao, *po, x0, y0, x, y, s, mu, st);
     });
@@ -213,48 +234,51 @@ int bz_alps_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po
 int bz_als_solve(bz_problem* p, const bz_alps_opts* ao, const bz_panoc_opts* po, const void* x0,
                  const void* y0, void* x, void* y, void* s, void* mu, bz_alps_stats* st) {
     return guard([&] {
-        need(p, "problem"); need(ao, "alps opts"); need(po, "panoc opts");
+        need(p, "problem"); on_device(p->device); need(ao, "alps opts"); need(po, "panoc opts");
         need(x0, "x0"); need(y0, "y0"); need(x, "x"); need(y, "y"); need(s, "s"); need(mu, "mu");
         p->s->als(*ao, *po, x0, y0, x, y, s, mu, st);
     });
 }
 
 int bz_eval_al_gradient(bz_problem* p, const void* x, void* dlx, double* vals3) {
-    return guard([&] { need(p, "problem"); need(x, "x"); need(vals3, "vals3"); p->s->eval_al_gradient(x, dlx, vals3); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(x, "x"); need(vals3, "vals3"); p->s->eval_al_gradient(x, dlx, vals3); });
 }
 int bz_eval_prox(bz_problem* p, const void* x, double gamma, void* z, double* gz) {
-    return guard([&] { need(p, "problem"); need(x, "x"); need(z, "z"); need(gz, "gz"); p->s->eval_prox(x, gamma, z, gz); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(x, "x"); need(z, "z"); need(gz, "gz"); p->s->eval_prox(x, gamma, z, gz); });
 }
 int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y, const void* v, void* d) {
     return guard([&] {
-        need(p, "problem"); need(v, "v"); need(d, "d");
+        need(p, "problem"); on_device(p->device); need(v, "v"); need(d, "d");
         if (m > 0) { need(S, "S"); need(Y, "Y"); }
         p->s->eval_lbfgs(m, S, Y, v, d);
     });
 }
 
 int bz_problem_halo_export(bz_problem* p, void* handle64) {
-    return guard([&] { need(p, "problem"); need(handle64, "handle64"); p->s->halo_export(handle64); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(handle64, "handle64"); p->s->halo_export(handle64); });
 }
 int bz_problem_halo_connect(bz_problem* p, const void* prev64, const void* next64) {
-    return guard([&] { need(p, "problem"); p->s->halo_connect(prev64, next64); });
+    return guard([&] { need(p, "problem"); on_device(p->device); p->s->halo_connect(prev64, next64); });
 }
 
 int bz_problem_allreduce_export(bz_problem* p, void* handle64) {
-    return guard([&] { need(p, "problem"); need(handle64, "handle64"); p->s->allreduce_export(handle64); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(handle64, "handle64"); p->s->allreduce_export(handle64); });
 }
 int bz_problem_allreduce_connect(bz_problem* p, const void* handles) {
-    return guard([&] { need(p, "problem"); need(handles, "handles"); p->s->allreduce_connect(handles); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(handles, "handles"); p->s->allreduce_connect(handles); });
 }
 
 int bz_profile_enable(bz_problem* p, int32_t on) {
-    return guard([&] { need(p, "problem"); p->s->profile_enable((unsigned)on); });
+    return guard([&] { need(p, "problem"); on_device(p->device); p->s->profile_enable((unsigned)on); });
 }
 int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms) {
-    return guard([&] { need(p, "problem"); need(launches, "launches"); need(total_ms, "total_ms"); p->s->profile_get(category, launches, total_ms); });
+    return guard([&] { need(p, "problem"); on_device(p->device); need(launches, "launches"); need(total_ms, "total_ms"); p->s->profile_get(category, launches, total_ms); });
+}
+int bz_profile_get2(bz_problem* p, int32_t category, bz_profile_rec* out) {
+    return guard([&] { need(p, "problem"); on_device(p->device); need(out, "out"); p->s->profile_get2(category, out); });
 }
 int bz_profile_reset(bz_problem* p) {
-    return guard([&] { need(p, "problem"); p->s->profile_reset(); });
+    return guard([&] { need(p, "problem"); on_device(p->device); p->s->profile_reset(); });
 }
 
 }  // extern "C"

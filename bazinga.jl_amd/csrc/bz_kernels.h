@@ -1387,7 +1387,7 @@ k_pack(const double* parts, SlotCounts counts, int first, int cnt, unsigned maxm
 constexpr int PBLOCK = 512;
 constexpr int PWAVES = PBLOCK / 64;
 constexpr int PMAXMEM = 16;
-constexpr unsigned PSPIN_LIMIT = 4000000u;
+constexpr unsigned PSPIN_LIMIT = 400000u;      // ~1.5 us per poll: gives up after about half a second
 
 template <class T> struct PersistArgs {
     const T* res;
@@ -1404,6 +1404,7 @@ template <class T> struct PersistArgs {
     unsigned long long* counter;
     unsigned long long base; // counter value when this launch starts
     int* timeout;            // host-visible flag, set if a spin gives up
+    unsigned long long* abort_flag;   // device word raised with it: the other workgroups (and the later phases) stop polling
     int slot_loop1, slot_loop2;
     // multi-GPU (x sharded): phase totals are exchanged through the peers' mailboxes
     int nranks, rank;
@@ -1449,7 +1450,8 @@ __device__ __forceinline__ void grid_arrive(double acc, double* row, unsigned lo
     }
 }
 __device__ __forceinline__ double grid_wait_fold(double* row, int nb, unsigned long long* counter,
-                                                 unsigned long long target, int* timeout, double* sh) {
+                                                 unsigned long long target, int* timeout, double* sh,
+                                                 unsigned long long* abort_flag = nullptr) {
     if (threadIdx.x < 64) {            // wave 0 polls: lanes 0..7 read one shard each
         unsigned spins = 0;
         for (;;) {
@@ -1468,7 +1470,18 @@ __device__ __forceinline__ double grid_wait_fold(double* row, int nb, unsigned l
             const unsigned long long tot = ((unsigned long long)__shfl(hi, 0, 64) << 32) | __shfl(lo, 0, 64);
             if (tot >= target) break;
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > PSPIN_LIMIT) { if (threadIdx.x == 0) *timeout = 1; break; }
+            ++spins;
+            // a grid whose workgroups are not all resident never completes this barrier: the first poller to give up
+            // tells the host and raises a device flag that ends everybody else's polling (this phase and the later ones)
+            if (abort_flag && (spins & 255u) == 255u &&
+                __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+            if (spins > PSPIN_LIMIT) {
+                if (threadIdx.x == 0) {
+                    *timeout = 1;
+                    if (abort_flag) __hip_atomic_store(abort_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: keep the loads below the poll
     }
@@ -1597,7 +1610,7 @@ k_twoloop_persist(PersistArgs<T> a) {
     unsigned long long target = a.base;
     unsigned long long q = a.pseq;          // multi-GPU: sequence number of the coming phase
     auto phase_total = [&](double* row) -> double {
-        if (a.nranks <= 1) return grid_wait_fold(row, nb, a.counter, target, a.timeout, sh);
+        if (a.nranks <= 1) return grid_wait_fold(row, nb, a.counter, target, a.timeout, sh, a.abort_flag);
         const double g = grid_wait_fold_multi(a, row, target, q, sh);
         ++q;
         return g;
@@ -2696,6 +2709,10 @@ k_fvalue_elem(const T* __restrict__ x, ElemParams<T> P, int64_t n, double* __res
 // ---------------------------------------------------------------------------
 // scalar plumbing
 // ---------------------------------------------------------------------------
+// one host-given number as a reduction slot with a single partial (so that it can travel through an exchange)
+static __global__ void __launch_bounds__(64) k_fill_slot(double* parts, int slot, double v) {
+    if (threadIdx.x == 0) parts[(size_t)slot * PSTRIDE] = v;
+}
 constexpr int MAX_COLLECT = 40;
 struct CollectArgs {
     ScalarSrc src[MAX_COLLECT];

@@ -129,6 +129,7 @@ struct SolverBase {
     virtual void profile_enable(unsigned mask) = 0;
     virtual void profile_get(int cat, int64_t* launches, double* ms) = 0;
     virtual void profile_reset() = 0;
+    virtual void profile_get2(int cat, bz_profile_rec* out) = 0;
 };
 
 void p2p_export(Ctx* ctx, void* handle64);

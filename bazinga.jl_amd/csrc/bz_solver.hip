@@ -90,8 +90,15 @@ __global__ void __launch_bounds__(64) k_collect_w(CollectArgs a, double* out) {
     if (threadIdx.x == 0) host_post(out, i, t, a.ticket);
 }
 
+// the persistent two-loop kernel's grid barrier gave up (its workgroups were not all resident): single-rank
+// solves catch this, switch to the kernel chain for good and redo the iteration
+struct PersistTimeout : Error {
+    PersistTimeout() : Error(BZ_ERR_HIP, "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)") {}
+};
+
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
-                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11, C_FUSED_IT = 12 };
+                 C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11, C_FUSED_IT = 12,
+                 C_STENCIL_FB = 13, C_STENCIL_UPD = 14, C_XD = 15 };
 
 template <class T> class Solver final : public SolverBase {
    public:
@@ -162,6 +169,10 @@ template <class T> class Solver final : public SolverBase {
             // are zero-padded to KR*num_cus*512 packs so that every round is in-bounds (no masks)
             const int64_t kneed = (nchunks + (int64_t)pblocks * PBLOCK - 1) / ((int64_t)pblocks * PBLOCK);
             persist_kr = (kneed <= 48 && pblocks > 0 && pblocks <= PSTRIDE) ? persist_round_kr((int)kneed) : 0;
+            // the hand-rolled grid barrier needs every workgroup resident at once: ask the runtime how many 512-thread
+            // workgroups of this instantiation fit a CU (a non-resident grid would spin until the bounded polls give
+            // up; that case — another process or stream holding CUs — is caught at run time, see step())
+            if (persist_kr && persist_occupancy(persist_kr) * num_cus < pblocks) persist_kr = 0;
             vcap = n;
             if (persist_kr) vcap = std::max<int64_t>(n, (int64_t)persist_kr * pblocks * PBLOCK * PackN<T>::N);
         }
@@ -360,8 +371,8 @@ template <class T> class Solver final : public SolverBase {
             const int slot = spare;
             copy_in(S_[slot].p, Sh + (size_t)i * n, n);
             copy_in(Y_[slot].p, Yh + (size_t)i * n, n);
-            launch(C_MISC, k_dot<T>, grid, (const T*)S_[slot].p, (const T*)Y_[slot].p, T(1), n, parts_.p, (int)SL_YS);
-            launch(C_MISC, k_dot<T>, grid, (const T*)Y_[slot].p, (const T*)Y_[slot].p, T(1), n, parts_.p, (int)SL_YTY);
+            mv(2); launch(C_MISC, k_dot<T>, grid, (const T*)S_[slot].p, (const T*)Y_[slot].p, T(1), n, parts_.p, (int)SL_YS);
+            mv(1); launch(C_MISC, k_dot<T>, grid, (const T*)Y_[slot].p, (const T*)Y_[slot].p, T(1), n, parts_.p, (int)SL_YTY);
             gather(SL_YS, 2, 0u);
             auto r = collect({SL_YS, SL_YTY}, 0u);
             lbfgs_insert((T)r[0], (T)r[1]);
@@ -372,6 +383,7 @@ template <class T> class Solver final : public SolverBase {
         for (int64_t i = 0; i < n; ++i) neg[i] = -vh[i];
         copy_in(RES_[rc].p, neg.data(), n);
         TailArgs<T> t = two_loop();
+        mv(t.mode != 2 ? 3 : 2);
         launch(C_TWOLOOP, k_axpy_dot<T>, grid, t, (const T*)nullptr, (const T*)nullptr, D_.p, n,
                parts_.p, 0);
         copy_out(d, D_.p, n);
@@ -384,7 +396,17 @@ template <class T> class Solver final : public SolverBase {
     }
     void profile_reset() override {
         drain_prof();
-        for (int c = 0; c < BZ_NUM_KERNEL_CATEGORIES; ++c) { prof_ms[c] = 0; prof_n[c] = 0; }
+        for (int c = 0; c < BZ_NUM_KERNEL_CATEGORIES; ++c) {
+            prof_ms[c] = 0; prof_n[c] = 0; bytes_all_[c] = 0; bytes_timed_[c] = 0; launches_all_[c] = 0;
+        }
+    }
+    void profile_get2(int cat, bz_profile_rec* r) override {
+        if (cat < 0 || cat >= BZ_NUM_KERNEL_CATEGORIES) throw Error(BZ_ERR_ARG, "bad category");
+        drain_prof();
+        std::memset(r, 0, sizeof(*r));
+        r->timed_launches = prof_n[cat]; r->timed_ms = prof_ms[cat]; r->timed_bytes = bytes_timed_[cat];
+        r->launches = launches_all_[cat]; r->bytes = bytes_all_[cat];
+        std::strncpy(r->form, form_[cat].c_str(), sizeof(r->form) - 1);
     }
     void profile_get(int cat, int64_t* launches, double* ms) override {
         if (cat < 0 || cat >= BZ_NUM_KERNEL_CATEGORIES) throw Error(BZ_ERR_ARG, "bad category");
@@ -413,6 +435,7 @@ template <class T> class Solver final : public SolverBase {
         const double denom = std::max(1.0, (double)objx);
         const bool dense_c = desc.c_kind == BZ_C_DENSE_AFFINE;
         if (dense_c) eval_c(x);
+        mv(3 + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0), ny);
         launch(C_MISC, k_penalty_init<T>, grid_y, dense_c ? (const T*)CX_.p : (const T*)x /* cx = x */, P, denom,
                sproj_.p, mu_.p, ny);
         copy_in(ymul_.p, y0, ny);                                    // y .= y0
@@ -442,6 +465,7 @@ template <class T> class Solver final : public SolverBase {
             const bool sub_solved = sub_it < ao.subsolver_maxit;     // alps.jl:70
             // dual update + primal residual                          alps.jl:72-84
             if (dense_c) eval_c(x);                                  // eval!(cx, c, x)  alps.jl:72
+            mv(3 + pstreams(false, true, false), ny);
             launch(C_MISC, k_dual_update<T>, grid_y, dense_c ? (const T*)CX_.p : (const T*)x, P, ymul_.p, sproj_.p,
                    ny, parts_.p, (int)SL_OUTER);
             gather(SL_OUTER, 1, 1u, 1u);
@@ -455,7 +479,7 @@ template <class T> class Solver final : public SolverBase {
             if (!can_stop) {
                 if (have_old &&
                     norm_res_prim > std::max(ao.theta_penalty * norm_res_prim_old, ao.tol_prim)) {
-                    launch(C_MISC, k_clamp_scale<T>, grid_y, mu_.p, 0.0, 0.0, (T)ao.kappa_penalty, 0, ny);
+                    mv(2, ny); launch(C_MISC, k_clamp_scale<T>, grid_y, mu_.p, 0.0, 0.0, (T)ao.kappa_penalty, 0, ny);
                 }
                 inner_tol = std::max(ao.kappa_tol * inner_tol, ao.tol_dual);
             }
@@ -489,6 +513,7 @@ template <class T> class Solver final : public SolverBase {
         T* xs = X_[0].p;                                   // [x; s]
         copy_in(TMP_.p, x0, nx);
         // prox!(x, gFun, x0, eps(T)) ; objx = f(x) + gFun.gz              als.jl:41-42
+        mv(2 + pstreams(false, false, true), nx);
         if (lp_g) launch(C_FB, k_fbstep<T, true>, grid_y, (const T*)TMP_.p, (const T*)nullptr, epsT, P, xs, (T*)nullptr, nx, parts_.p, (int)SL_GSUM);
         else launch(C_FB, k_fbstep<T, false>, grid_y, (const T*)TMP_.p, (const T*)nullptr, epsT, P, xs, (T*)nullptr, nx, parts_.p, (int)SL_GSUM);
         for (int k = 0; k < 3; ++k) slot_n[SL_GSUM + k] = grid_y;
@@ -496,6 +521,7 @@ template <class T> class Solver final : public SolverBase {
         auto v0 = collect({SL_GSUM, SL_AUX}, 0u);
         T objx = f_value(v0[1]) + g_value(v0[0]);
         // eval!(cx,c,x); proj!(s,D,cx); default_penalty_parameter!          als.jl:43-45   (s lands in xs[nx:])
+        mv(3 + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0), ny);
         launch(C_MISC, k_penalty_init<T>, grid_y, (const T*)xs, P, std::max(1.0, (double)objx), xs + nx, mu_.p, ny);
         copy_in(ymul_.p, y0, ny);
         double norm_res_prim = 0, norm_res_prim_old = 0;
@@ -518,6 +544,7 @@ template <class T> class Solver final : public SolverBase {
             tot_inner += sub_it;
             const bool sub_solved = sub_it < ao.subsolver_maxit;
             // y += (cx - s)/mu ; ||cx - s||_inf                      als.jl:82-87
+            mv(5, nx);
             launch(C_MISC, k_dual_update_slack<T>, grid_y, (const T*)xs, (const T*)mu_.p, ymul_.p, nx, parts_.p,
                    (int)SL_OUTER);
             slot_n[SL_OUTER] = grid_y;
@@ -530,8 +557,9 @@ template <class T> class Solver final : public SolverBase {
             broken = std::isnan((double)objx);
             can_stop = solved || tired || broken;
             if (!can_stop) {
-                if (have_old && norm_res_prim > std::max(ao.theta_penalty * norm_res_prim_old, ao.tol_prim))
-                    launch(C_MISC, k_clamp_scale<T>, grid_y, mu_.p, 0.0, 0.0, (T)ao.kappa_penalty, 0, ny);
+                if (have_old && norm_res_prim > std::max(ao.theta_penalty * norm_res_prim_old, ao.tol_prim)) {
+                    mv(2, ny); launch(C_MISC, k_clamp_scale<T>, grid_y, mu_.p, 0.0, 0.0, (T)ao.kappa_penalty, 0, ny);
+                }
                 inner_tol = std::max(ao.kappa_tol * inner_tol, ao.tol_dual);
                 BZ_HIP(hipMemcpyAsync(X_[0].p, xs, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
                 xs = X_[0].p;
@@ -581,6 +609,8 @@ template <class T> class Solver final : public SolverBase {
     int num_cus = 0, persist_kr = 0;
     int64_t vcap = 0;                        // allocated elements per n-vector (>= n, zero-padded)
     bool persist_ok = false;
+    bool persist_broken_ = false;            // a grid barrier timed out once on this problem: the kernel chain from then on
+    bool persist_sabotage_ = false;          // BZ_TEST_PERSIST_TIMEOUT=1: make the barrier miss its target (tests the fallback)
     std::vector<DBuf<T>> S_, Y_;
     DBuf<double> parts_, alphas_, send_, recv_;
     double* host_out_ = nullptr;             // pinned mailbox: {value, ticket} per collected scalar
@@ -629,10 +659,12 @@ template <class T> class Solver final : public SolverBase {
         for (int i = 0; i < m; ++i) { V.S[i] = S_[order[m - 1 - i]].p; V.Y[i] = Y_[order[m - 1 - i]].p; }
         if (rh_stale_) {
             // (must run before gamma changes: the residuals are re-evaluated with the gamma of this run)
+            mv((m + 1) + 4 + 2 * m + 2);
             launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, m, P, RES_[rc].p, Z_[zc].p, n);
             res_valid = true; z_valid = true;
         } else {
             if (m != CM) throw Error(BZ_ERR_STATE, "history as snapshots with a partial memory");
+            mv(2 * (CM + 1) + 2 * CM);
             launch(C_MISC, k_pairs_from_snapshots<T, CM>, grid, V, n);
         }
         sy_stale_ = false;
@@ -664,8 +696,34 @@ template <class T> class Solver final : public SolverBase {
     double hp_[CM] = {0}, hw_[CM] = {0};
 
     // profiling
-    struct ProfRec { int cat; hipEvent_t a, b; };
+    struct ProfRec { int cat; hipEvent_t a, b; double bytes; };
     unsigned prof_mask = 0, prof_period = 1;
+    // Bytes every launch is DESIGNED to move (its read + write streams x their length x sizeof(T)), noted by mv()
+    // right before the launch: counted for every launch of a category (bytes_all_) and for the launches that
+    // carry timing events (bytes_timed_), so that a sustained rate is moved bytes / measured time of the SAME
+    // launches whatever mix of kernel forms ran.  form_[cat]: template form of the category's last launch.
+    double pending_bytes_ = 0.0;
+    const char* pending_form_ = nullptr;
+    void nm(const char* kernel_name) { pending_form_ = kernel_name; }
+    double bytes_all_[BZ_NUM_KERNEL_CATEGORIES] = {0}, bytes_timed_[BZ_NUM_KERNEL_CATEGORIES] = {0};
+    int64_t launches_all_[BZ_NUM_KERNEL_CATEGORIES] = {0};
+    std::string form_[BZ_NUM_KERNEL_CATEGORIES];
+    void mv(double passes, int64_t len = -1) { pending_bytes_ += passes * (double)(len < 0 ? n : len) * sizeof(T); }
+    // parameter vectors an element-wise kernel streams (load_params)
+    int pstreams(bool need_f, bool need_al, bool need_g) const {
+        int k = 0;
+        if (need_f && P.f_kind == BZ_F_DIAG_QUADRATIC) k += 2;
+        if (need_al) k += 2 + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0);
+        if (need_g) k += (P.g_u && (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX || P.g_kind == BZ_G_NORM_LP_BOX) ? 1 : 0) +
+                         (P.g_lo_vec ? 1 : 0) + (P.g_hi_vec ? 1 : 0);
+        return k;
+    }
+    void account(int cat, ProfRec* r) {
+        bytes_all_[cat] += pending_bytes_; launches_all_[cat] += 1;
+        if (r) r->bytes = pending_bytes_;
+        pending_bytes_ = 0.0;
+        if (pending_form_) { form_[cat] = pending_form_; pending_form_ = nullptr; }
+    }
     unsigned prof_count[BZ_NUM_KERNEL_CATEGORIES] = {0};
     bool prof_pick(int cat) {
         if (!((prof_mask >> cat) & 1u)) return false;
@@ -685,7 +743,7 @@ template <class T> class Solver final : public SolverBase {
         BZ_HIP(hipStreamSynchronize(ctx->stream));
         for (auto& r : prof_recs) {
             float ms = 0; BZ_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-            prof_ms[r.cat] += ms; prof_n[r.cat] += 1;
+            prof_ms[r.cat] += ms; prof_n[r.cat] += 1; bytes_timed_[r.cat] += r.bytes;
             ev_pool.push_back(r.a); ev_pool.push_back(r.b);
         }
         prof_recs.clear();
@@ -695,8 +753,9 @@ template <class T> class Solver final : public SolverBase {
         launch_b(cat, kernel, g, BLOCK, args...);
     }
     template <class K, class... A> void launch_b(int cat, K kernel, int g, int block, A... args) {
-        ProfRec r{cat, nullptr, nullptr};
+        ProfRec r{cat, nullptr, nullptr, 0.0};
         const bool prof_on = prof_pick(cat);
+        account(cat, prof_on ? &r : nullptr);
         if (prof_on) {
             // start/stop events bound to the dispatch itself: kernel time without the launch gap
             r.a = get_event(); r.b = get_event();
@@ -710,8 +769,10 @@ template <class T> class Solver final : public SolverBase {
     }
 
     template <class K, class... A> void launch2d(int cat, K kernel, int gx, int gy, A... args) {
-        ProfRec r{cat, nullptr, nullptr};
-        if (prof_pick(cat)) {
+        ProfRec r{cat, nullptr, nullptr, 0.0};
+        const bool prof_on = prof_pick(cat);
+        account(cat, prof_on ? &r : nullptr);
+        if (prof_on) {
             r.a = get_event(); r.b = get_event();
             hipExtLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, ctx->stream, r.a, r.b, 0, args...);
             prof_recs.push_back(r);
@@ -877,6 +938,7 @@ template <class T> class Solver final : public SolverBase {
         const int fb_env = fused_begin_env_;
         if (fb_env && desc.c_kind == BZ_C_IDENTITY && !slack && !dense_f && !lp_g &&
             (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC)) {
+            mv(1 + pstreams(true, true, true) + 1 + (res_valid ? 0 : 1));
             launch(C_FB, k_zres_elem<T>, grid, (const T*)X_[xc].p, P, gamma, Z_[zc].p,
                    res_valid ? (T*)nullptr : RES_[rc].p, n);      // the two kernels below in one pass
         } else {
@@ -990,6 +1052,7 @@ template <class T> class Solver final : public SolverBase {
         if (*ptimeout_) {
             const int code = *ptimeout_;
             *ptimeout_ = 0;
+            if (code == 1 && ctx->nranks == 1) throw PersistTimeout();
             throw Error(code == 1 ? BZ_ERR_HIP : BZ_ERR_COMM,
                         code == 1 ? "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)"
                         : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
@@ -1011,11 +1074,13 @@ template <class T> class Solver final : public SolverBase {
     void fbstep(const T* x, const T* g, T gam, T* z, T* res, int slot0) {
         if (slack) {
             for (int k = 0; k < 3; ++k) slot_n[slot0 + k] = grid_y;
+            mv(2 * (1 + (g ? 1 : 0) + 1 + (res ? 1 : 0)) + pstreams(false, false, true) + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0), nx);
             if (lp_g) launch(C_FB, k_fbstep_slack<T, true>, grid_y, x, g, gam, P, z, res, nx, parts_.p, slot0);
             else launch(C_FB, k_fbstep_slack<T, false>, grid_y, x, g, gam, P, z, res, nx, parts_.p, slot0);
             return;
         }
         for (int k = 0; k < 3; ++k) slot_n[slot0 + k] = grid;
+        mv(1 + (g ? 1 : 0) + 1 + (res ? 1 : 0) + pstreams(false, false, true));
         if (lp_g) launch(C_FB, k_fbstep<T, true>, grid, x, g, gam, P, z, res, n, parts_.p, slot0);
         else launch(C_FB, k_fbstep<T, false>, grid, x, g, gam, P, z, res, n, parts_.p, slot0);
     }
@@ -1045,6 +1110,8 @@ template <class T> class Solver final : public SolverBase {
     }
     // out = M p - b (b may be null): M[rows][n] row-major
     void gemv_rows(const T* M, int64_t rows, const T* p, const T* b, T* out) {
+        mv((double)rows, n); mv(b ? 2 : 1, rows); mv(1, n);      // the matrix once, x, b and the result
+        nm("k_gemv_n");
         launch(C_GEMV, k_gemv_n<T>, (int)std::min<int64_t>(rows, 65535), M, p, b, out, rows, n);
     }
     // GT_ partials of M' v over row chunks.  fp32 with n % 64 == 0 runs on the matrix cores
@@ -1052,6 +1119,8 @@ template <class T> class Solver final : public SolverBase {
     void gemv_cols(const T* M, int64_t rows, const T* v, int rpc, int nch) {
         if constexpr (std::is_same<T, float>::value) {
             if (n % 64 == 0 && !getenv("BZ_GEMV_VALU")) {
+                mv((double)rows, n); mv(1, rows); mv(nch, npad);      // the matrix once, v, the row-chunk partials
+                nm("k_gemv_t_mfma");
                 launch2d(C_GEMV_MFMA, k_gemv_t_mfma, (int)((n / 64 + WAVES - 1) / WAVES), nch, (const float*)M,
                          (const float*)v, (float*)GT_.p, rows, n, rpc, npad);
                 return;
@@ -1059,6 +1128,7 @@ template <class T> class Solver final : public SolverBase {
         }
         const bool aligned = (n % PackN<T>::N) == 0;
         const int colblocks = (int)(((aligned ? n / PackN<T>::N : n) + BLOCK - 1) / BLOCK);
+        mv((double)rows, n); mv(1, rows); mv(nch, npad); nm("k_gemv_t");
         launch2d(C_GEMV, k_gemv_t<T>, colblocks, nch, M, v, GT_.p, rows, n, rpc, npad);
     }
     // eval!(cx, c, x) for the dense constraint
@@ -1070,12 +1140,14 @@ template <class T> class Solver final : public SolverBase {
         if (desc.f_kind == BZ_F_LEAST_SQUARES) {
             gemv_rows(FA_.p, frows, x, fb_.p, FR_.p);
             const int gm = (int)std::min<int64_t>(grid, std::max<int64_t>(1, (frows / PackN<T>::N + BLOCK) / BLOCK));
+            mv(1, frows);
             launch(C_MISC, k_dot<T>, gm, (const T*)FR_.p, (const T*)FR_.p, T(1), frows, parts_.p, slot0);
             slot_n[slot0] = gm;
             if (need_grad) {
                 gemv_cols(FA_.p, frows, FR_.p, f_rows_per_chunk, f_nrowchunks);
                 ElemParams<T> Pz = P;
                 Pz.f_kind = BZ_F_ZERO;
+                mv(f_nrowchunks + 2);
                 launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, f_nrowchunks, npad, x, Pz, DFX_.p, n,
                        parts_.p, (int)SL_SCRATCH);
             }
@@ -1086,6 +1158,7 @@ template <class T> class Solver final : public SolverBase {
     void algrad(const T* x, T* grad, int slot0) {
         if (desc.c_kind == BZ_C_DENSE_AFFINE) {
             eval_c(x);                                                        // cx = A x - b
+            mv(2 + pstreams(false, true, false), ny);
             launch(C_MISC, k_yupd<T>, grid_y, (const T*)CX_.p, P, YU_.p, ny, parts_.p, slot0 + 1);
             slot_n[slot0] = grid; slot_n[slot0 + 1] = grid_y;
             gemv_cols(A_.p, ny, YU_.p, rows_per_chunk, nrowchunks);           // jtv = A' yupd (row-chunk partials)
@@ -1093,11 +1166,14 @@ template <class T> class Solver final : public SolverBase {
                 // this rank's rows only: fold the chunks, sum over the ranks (rank order), then finish
                 ElemParams<T> Pz = P;
                 Pz.f_kind = BZ_F_ZERO;
+                mv(nrowchunks + 2);
                 launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, npad, x, Pz, JL_.p, n, parts_.p,
                        (int)SL_SCRATCH);
                 const T* chunks = allreduce_partials();
+                mv(ctx->nranks + 2 + pstreams(true, false, false));
                 launch(C_MISC, k_gemv_t_finish<T>, grid, chunks, ctx->nranks, npad, x, P, grad, n, parts_.p, slot0);
             } else {
+                mv(nrowchunks + 2 + pstreams(true, false, false));
                 launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, nrowchunks, npad, x, P, grad, n, parts_.p, slot0);
             }
             gather(slot0, 2, 0u, 2u);         // slot0: f terms (x-space) ; slot0 + 1: penalty terms (this rank's rows)
@@ -1106,6 +1182,7 @@ template <class T> class Solver final : public SolverBase {
         slot_n[slot0] = slot_n[slot0 + 1] = grid;
         if (slack) {
             slot_n[slot0] = slot_n[slot0 + 1] = grid_y;
+            mv(2 + pstreams(true, false, false) + 3 + 2, nx);
             launch(C_ALGRAD, k_algrad_slack_elem<T>, grid_y, x, P, (const T*)ymul_.p, grad, nx, parts_.p, slot0);
             gather(slot0, 2, 0u);
             return;
@@ -1113,13 +1190,15 @@ template <class T> class Solver final : public SolverBase {
         if (dense_f) {
             dense_f_eval(x, slot0, true);
             if (desc.f_kind == BZ_F_LEAST_SQUARES)
-                launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 1, (const T*)DFX_.p);
+                { mv(3 + pstreams(false, true, false)); launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 1, (const T*)DFX_.p); }
             else
-                launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 2, (const T*)FR_.p);
+                { mv(4 + pstreams(false, true, false)); launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 2, (const T*)FR_.p); }
         } else if (desc.f_kind == BZ_F_STENCIL5) {
+            mv(3 + pstreams(false, true, false));      // x (its north / south / west / east re-reads are cache hits), b, grad
             launch(C_ALGRAD, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 0,
                    grad, n, parts_.p, slot0, halo_exchange(x));
         } else {
+            mv(2 + pstreams(true, true, false));
             launch(C_ALGRAD, k_algrad_elem<T>, grid, x, P, grad, n, parts_.p, slot0, 0, (const T*)nullptr);
         }
         gather(slot0, 2, 0u);
@@ -1129,6 +1208,7 @@ template <class T> class Solver final : public SolverBase {
         slot_n[slot0] = grid;
         if (slack) {      // f on the x part only
             slot_n[slot0] = grid_y;
+            mv(1 + pstreams(true, false, false), nx);
             launch(C_MISC, k_fvalue_elem<T>, grid_y, x, P, nx, parts_.p, slot0, (const T*)nullptr);
             gather(slot0, 1, 0u);
             return;
@@ -1136,11 +1216,13 @@ template <class T> class Solver final : public SolverBase {
         if (dense_f) {
             dense_f_eval(x, slot0, false);
             if (desc.f_kind == BZ_F_QUADRATIC)
-                launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0, (const T*)FR_.p);
+                { mv(3); launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0, (const T*)FR_.p); }
         } else if (desc.f_kind == BZ_F_STENCIL5) {
+            mv(2);
             launch(C_MISC, k_algrad_stencil<T>, grid, x, P, (int64_t)desc.f_grid_nx, (int64_t)desc.f_grid_ny, 1,
                    (T*)nullptr, n, parts_.p, slot0, halo_exchange(x));
         } else {
+            mv(1 + pstreams(true, false, false));
             launch(C_MISC, k_fvalue_elem<T>, grid, x, P, n, parts_.p, slot0, (const T*)nullptr);
         }
         gather(slot0, 1, 0u);
@@ -1156,6 +1238,7 @@ template <class T> class Solver final : public SolverBase {
         const int uni_env = std::getenv("BZ_UNI") ? std::atoi(std::getenv("BZ_UNI")) : 2;      // (tests toggle it)
         const bool probe = uni_env && fused_family();
         for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
+        mv(3 + (safeguard ? 1 : 0), ny);
         launch(C_MISC, k_muy<T>, grid_y, (const T*)mu_.p, ymul_.p, muy_.p, ny, parts_.p, (int)SL_OUTER,
                safeguard ? 1 : 0, probe ? (int)SL_GP : -1);
         gather(SL_OUTER, 2, 2u, 3u);
@@ -1272,6 +1355,7 @@ template <class T> class Solver final : public SolverBase {
         }
         if (!pw_valid) {
             for (int k = 0; k < 2 * CM; ++k) slot_n[SL_GP + k] = grid;
+            mv(2 * m + 1);
             launch(C_DOT, k_gram_dots<T, CM>, grid, V, (const T*)RES_[rc].p, n, parts_.p, (int)SL_GP);
             gather(SL_GP, 2 * CM, 0u);
             auto pv = collect({SL_GP + 0, SL_GP + 1, SL_GP + 2, SL_GP + 3, SL_GP + 4, SL_GP + 5, SL_GP + 6,
@@ -1323,7 +1407,8 @@ template <class T> class Solver final : public SolverBase {
         a.res = RES_[rc].p;
         for (int j = 0; j < m; ++j) { a.S[j] = S_[order[j]].p; a.Y[j] = Y_[order[j]].p; a.ys[j] = ys_[order[j]]; }
         a.H = H; a.m = m; a.d_out = D_.p; a.n = n; a.parts = parts_.p; a.alphas = alphas_.p;
-        a.counter = pcounter_.p; a.base = pbase; a.timeout = ptimeout_dev_;
+        a.counter = pcounter_.p; a.base = pbase + (persist_sabotage_ ? 1ull : 0ull); a.timeout = ptimeout_dev_;
+        a.abort_flag = pgflag_.p + 1;
         a.slot_loop1 = SL_LOOP1; a.slot_loop2 = SL_LOOP2;
         a.nb = persist_blocks();
         const bool multi = ctx->nranks > 1;
@@ -1336,6 +1421,8 @@ template <class T> class Solver final : public SolverBase {
             ctx->pseq += nphases;
         }
         pbase += (unsigned long long)nphases * a.nb;
+        mv(4 * m, vcap);
+        form_[C_PERSIST] = "k_twoloop_persist<KR=" + std::to_string(persist_kr) + ">";
         switch (persist_kr) {
 #define BZ_KR_CASE(K) case K: launch_persist(k_twoloop_persist<T, K>, a); break;
         BZ_KR_CASE(1) BZ_KR_CASE(2) BZ_KR_CASE(3) BZ_KR_CASE(4) BZ_KR_CASE(5) BZ_KR_CASE(6) BZ_KR_CASE(7) BZ_KR_CASE(8)
@@ -1351,6 +1438,20 @@ template <class T> class Solver final : public SolverBase {
         return t;
     }
     int persist_blocks() const { return pblocks; }
+    static int persist_occupancy(int kr) {
+        int nb = 0;
+        hipError_t e = hipErrorInvalidValue;
+        switch (kr) {
+#define BZ_KR_CASE(K) case K: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_twoloop_persist<T, K>, PBLOCK, 0); break;
+        BZ_KR_CASE(1) BZ_KR_CASE(2) BZ_KR_CASE(3) BZ_KR_CASE(4) BZ_KR_CASE(5) BZ_KR_CASE(6) BZ_KR_CASE(7) BZ_KR_CASE(8)
+        BZ_KR_CASE(10) BZ_KR_CASE(12) BZ_KR_CASE(14) BZ_KR_CASE(16) BZ_KR_CASE(20) BZ_KR_CASE(24) BZ_KR_CASE(28)
+        BZ_KR_CASE(32) BZ_KR_CASE(36) BZ_KR_CASE(40) BZ_KR_CASE(44) BZ_KR_CASE(48)
+#undef BZ_KR_CASE
+        default: break;
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return nb;
+    }
     // register packs per thread: the smallest instantiated count >= the need (rounds past the need
     // stream zero padding, so the steps are finer where the relative waste would be larger)
     static int persist_round_kr(int kneed) {
@@ -1359,8 +1460,10 @@ template <class T> class Solver final : public SolverBase {
         return 0;
     }
     template <class K> void launch_persist(K kernel, const PersistArgs<T>& a) {
-        ProfRec r{C_PERSIST, nullptr, nullptr};
-        if (prof_pick(C_PERSIST)) {
+        ProfRec r{C_PERSIST, nullptr, nullptr, 0.0};
+        const bool prof_on = prof_pick(C_PERSIST);
+        account(C_PERSIST, prof_on ? &r : nullptr);
+        if (prof_on) {
             r.a = get_event(); r.b = get_event();
             hipExtLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, ctx->stream, r.a, r.b, 0, a);
             prof_recs.push_back(r);
@@ -1382,6 +1485,7 @@ template <class T> class Solver final : public SolverBase {
             t.src = ScalarSrc{parts_.p, 0, 1}; t.ys = T(1);
             return t;
         }
+        mv(2);
         launch(C_DOT, k_dot<T>, grid, (const T*)S_[order[0]].p, res, T(-1), n, parts_.p, SL_LOOP1 + 0);
         gather(SL_LOOP1 + 0, 1, 0u);
         for (int j = 0; j + 1 < m; ++j) {        // loop 1: d -= alpha_j y_j ; <s_{j+1}, d>
@@ -1389,6 +1493,7 @@ template <class T> class Solver final : public SolverBase {
             a.in = (j == 0) ? res : (const T*)D_.p; a.sgn = (j == 0) ? T(-1) : T(1);
             a.v = Y_[order[j]].p; a.mode = 0; a.j = j; a.apply_H = 0; a.H = T(1);
             a.src = src(SL_LOOP1 + j); a.ys = ys_[order[j]];
+            mv(4); nm("k_axpy_dot");
             launch(C_TWOLOOP, k_axpy_dot<T>, grid, a, (const T*)S_[order[j + 1]].p, (const T*)nullptr,
                    D_.p, n, parts_.p, SL_LOOP1 + j + 1);
             gather(SL_LOOP1 + j + 1, 1, 0u);
@@ -1399,6 +1504,7 @@ template <class T> class Solver final : public SolverBase {
             a.in = (m == 1) ? res : (const T*)D_.p; a.sgn = (m == 1) ? T(-1) : T(1);
             a.v = Y_[order[j]].p; a.mode = 0; a.j = j; a.apply_H = 1; a.H = H;
             a.src = src(SL_LOOP1 + j); a.ys = ys_[order[j]];
+            mv(3);
             launch(C_TWOLOOP, k_axpy_dot<T>, grid, a, (const T*)Y_[order[j]].p, (const T*)nullptr, D_.p,
                    n, parts_.p, SL_LOOP2 + j);
             gather(SL_LOOP2 + j, 1, 0u);
@@ -1407,6 +1513,7 @@ template <class T> class Solver final : public SolverBase {
             TailArgs<T> a = t;
             a.in = D_.p; a.sgn = T(1); a.v = S_[order[j]].p; a.mode = 1; a.j = j; a.apply_H = 0;
             a.H = T(1); a.src = src(SL_LOOP2 + j); a.ys = ys_[order[j]];
+            mv(4);
             launch(C_TWOLOOP, k_axpy_dot<T>, grid, a, (const T*)Y_[order[j - 1]].p, (const T*)nullptr,
                    D_.p, n, parts_.p, SL_LOOP2 + j - 1);
             gather(SL_LOOP2 + j - 1, 1, 0u);
@@ -1439,9 +1546,20 @@ template <class T> class Solver final : public SolverBase {
             int64_t min_n = 300000;      // below this 2m short launches beat 2m-1 grid barriers (~5 us each)
             if (const char* e = getenv("BZ_PERSIST_MIN_N")) min_n = atoll(e);
             // with several ranks the phases need the p2p mailboxes (RCCL cannot be called from a kernel)
-            persist_ok = o.persist && (!ctx->multi() || ctx->p2p_on) && persist_kr > 0 && n >= min_n && !x_replicated;
+            persist_ok = o.persist && (!ctx->multi() || ctx->p2p_on) && persist_kr > 0 && n >= min_n && !x_replicated &&
+                         !persist_broken_;
             if (ctx->nranks > 1 && !ctx->multi())
                 throw Error(BZ_ERR_STATE, "nranks > 1 needs an RCCL communicator or connected p2p mailboxes");
+            persist_sabotage_ = std::getenv("BZ_TEST_PERSIST_TIMEOUT") && std::atoi(std::getenv("BZ_TEST_PERSIST_TIMEOUT")) != 0;
+            if (ctx->nranks > 1 && o.persist && M >= 1) {
+                // the shards may straddle a threshold (length, register budget): the phases of the persistent kernel
+                // and the exchanges of the kernel chain do not talk to each other, so all ranks must take the same
+                // form — the persistent one only if every rank can
+                launch_b(C_MISC, k_fill_slot, 1, 64, parts_.p, (int)SL_AUX, persist_ok ? 0.0 : 1.0);
+                slot_n[SL_AUX] = 1;
+                gather(SL_AUX, 1, 1u);
+                if (collect({SL_AUX}, 1u)[0] > 0.0) persist_ok = false;
+            }
         }
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;
@@ -1462,14 +1580,17 @@ template <class T> class Solver final : public SolverBase {
             (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC)) {
             // gradient at x and the Lipschitz estimate in one pass (k_begin_lip)
             slot_n[SL_FXD] = slot_n[SL_FXD + 1] = grid;
+            mv(2 + pstreams(true, true, false));
             launch(C_ALGRAD, k_begin_lip<T>, grid, (const T*)x, P, GX_.p, n, parts_.p, (int)SL_FXD, (int)SL_AUX);
             gather(SL_FXD, 2, 0u);
             n_grad += 2; gx_valid = true;
         } else {
             algrad(x, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
             // gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad_f_x)
+            mv(2);
             launch(C_MISC, k_add_scalar<T>, grid, (const T*)x, T(1), TMP_.p, n);
             algrad(TMP_.p, GZ_.p, SL_FZ); ++n_grad;
+            mv(4);
             launch(C_MISC, k_diff_ss2<T>, grid, (const T*)GZ_.p, (const T*)GX_.p, (const T*)TMP_.p, (const T*)x, n,
                    parts_.p, (int)SL_AUX);
         }
@@ -1491,6 +1612,7 @@ template <class T> class Solver final : public SolverBase {
             if (fused_fb) {
                 // FB step, gradient at z and stop norm in one pass (k_begin_fb)
                 for (int k = 0; k < 8; ++k) slot_n[SL_GSUM + k] = grid;
+                mv(4 + pstreams(true, true, true));
                 launch(C_FB, k_begin_fb<T>, grid, (const T*)x, (const T*)GX_.p, gamma, P, Z_[zc].p, RES_[rc].p, n,
                        parts_.p, (int)SL_GSUM);
                 gather(SL_GSUM, 8, 1u << 7);
@@ -1521,6 +1643,7 @@ template <class T> class Solver final : public SolverBase {
             stop_norm_ = stop0;
         } else {
             for (int k = 0; k < 3; ++k) slot_n[SL_YS + k] = grid;
+            mv(4);
             launch(C_UPDATE, k_update<T>, grid, (const T*)x, (const T*)nullptr, (const T*)RES_[rc].p,
                    (const T*)nullptr, (const T*)GX_.p, (const T*)GZ_.p, gamma, (T*)nullptr, (T*)nullptr, n,
                    parts_.p, (int)SL_YS);
@@ -1543,6 +1666,7 @@ template <class T> class Solver final : public SolverBase {
 
     void display() {
         ensure_z();
+        mv(1);
         launch(C_MISC, k_absmax<T>, grid, (const T*)RES_[rc].p, n, parts_.p, (int)SL_AUX);
         gather(SL_AUX, 1, 1u);
         auto v = collect({SL_AUX}, 1u);
@@ -1554,6 +1678,32 @@ template <class T> class Solver final : public SolverBase {
    public:
     void step() override {
         require_active();
+        if (!persist_ok) { step_impl(); return; }
+        // a grid barrier of the persistent two-loop kernel that cannot complete (its workgroups are not all
+        // resident: another stream or process holds CUs) is reported through the next read-back; nothing of the
+        // state has been committed by then, so the iteration is simply redone with the kernel chain, and the
+        // persistent form stays off for this problem
+        const int64_t sv[7] = {k_, n_grad, n_prox, n_bt, n_halv, n_fused, n_skips};
+        const unsigned long long sv_pseq = ctx->pseq;
+        try {
+            step_impl();
+        } catch (const PersistTimeout&) {
+            BZ_HIP(hipStreamSynchronize(ctx->stream));
+            *ptimeout_ = 0;
+            BZ_HIP(hipMemsetAsync(pcounter_.p, 0, PSHARDS * PSHARD_STRIDE * sizeof(unsigned long long), ctx->stream));
+            BZ_HIP(hipMemsetAsync(pgflag_.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+            BZ_HIP(hipStreamSynchronize(ctx->stream));
+            pbase = 0; ctx->pseq = sv_pseq;
+            k_ = sv[0]; n_grad = sv[1]; n_prox = sv[2]; n_bt = sv[3]; n_halv = sv[4]; n_fused = sv[5]; n_skips = sv[6];
+            gx_valid = false; gz_valid = false;
+            persist_ok = false; persist_broken_ = true; ++n_persist_fallbacks_;
+            std::fprintf(stderr, "Warning: persistent two-loop kernel timed out at its grid barrier; using the kernel chain\n");
+            step_impl();
+        }
+    }
+    int64_t n_persist_fallbacks_ = 0;
+   private:
+    void step_impl() {
         ++k_;
         const T eps = std::numeric_limits<T>::epsilon();
         const int max_bt = opt.max_backtracks;
@@ -1657,6 +1807,9 @@ template <class T> class Solver final : public SolverBase {
     launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,        \
            (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p,     \
            (int)SL_TRIAL)
+                // streams: the m_now + 1 distinct iterates (x among them), q, b, mu / mu*y unless passed as numbers; x_d (z)
+                mv((m_now + 1) + 2 + (2 - uni) + 1 + (zstore ? 1 : 0));
+                form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + char('0' + uni) + (nt ? ",NT=1" : ",NT=0") + ",TRIAL=0>";
                 if (nt) { if (uni == 2) BZ_LAUNCH_FC2(true, 2); else if (uni == 1) BZ_LAUNCH_FC2(true, 1); else BZ_LAUNCH_FC2(true, 0); }
                 else { if (uni == 2) BZ_LAUNCH_FC2(false, 2); else if (uni == 1) BZ_LAUNCH_FC2(false, 1); else BZ_LAUNCH_FC2(false, 0); }
 #undef BZ_LAUNCH_FC2
@@ -1670,6 +1823,8 @@ template <class T> class Solver final : public SolverBase {
                     XV.S[i] = X_[(xc - CM + i + NXR) % NXR].p;
                     XV.Y[i] = RES_[(rc - CM + i + NRR) % NRR].p;
                 }
+                mv(2 * (CM + 1) + 4 + 2 + (zstore ? 1 : 0));
+                form_[C_FUSED] = std::string("k_fused_compact<XR=1") + (nt ? ",NT=1>" : ",NT=0>");
                 if (nt)
                     launch(C_FUSED, k_fused_compact<T, CM, true, true, true, 1>, gfc, XV, CC, (const T*)X_[xp].p,
                            (const T*)RES_[rp].p, P, gamma, X_[xd].p, zstore, RES_[rn].p, (T*)nullptr, (T*)nullptr, n, parts_.p,
@@ -1683,6 +1838,11 @@ template <class T> class Solver final : public SolverBase {
 #define BZ_LAUNCH_FC3(NT_)                                                                                        \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, true, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
+            {
+                // stored pairs: res, S[m], Y[m], x + the parameter vectors ; x_d, res, s_new, y_new (z)
+                mv(2 + 2 * CV.m + pstreams(true, true, true) + 4 + (zstore ? 1 : 0));
+                form_[C_FUSED] = std::string("k_fused_compact<XR=0") + (spec ? ",SPEC=1" : ",SPEC=0") + (nt ? ",NT=1>" : ",NT=0>");
+            }
             if (off32 && nt) BZ_LAUNCH_FC3(true);
             else if (off32) BZ_LAUNCH_FC3(false);
             else if (nt && spec) BZ_LAUNCH_FC(true, true);
@@ -1703,6 +1863,8 @@ template <class T> class Solver final : public SolverBase {
         } else if (fused_ok) {
             if (!res_valid) ensure_z();
             for (int k = 0; k < 12; ++k) slot_n[SL_TRIAL + k] = grid;
+            mv((tail.mode != 2 ? 2 : 1) + 2 + pstreams(true, true, true) + 5);
+            form_[C_FUSED] = "k_fused_sep";
             launch(C_FUSED, k_fused_sep<T>, grid, tail, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, gamma,
                    X_[xd].p, Z_[zn].p, RES_[rn].p, S_[spare].p, Y_[spare].p, (T*)nullptr, (T*)nullptr, n,
                    parts_.p, (int)SL_TRIAL);
@@ -1713,20 +1875,27 @@ template <class T> class Solver final : public SolverBase {
         } else {
             if (!res_valid) ensure_z();
             // x_d = x + d ; gradient at x_d ; state.x = x_d
-            if (use_compact)
-                launch(C_TWOLOOP, k_compact_xd<T, CM>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p,
+            if (use_compact) {
+                mv(2 * CV.m + 3); nm("k_compact_xd");
+                launch(C_XD, k_compact_xd<T, CM>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p,
                        X_[xd].p, n);
-            else
-                launch(C_TWOLOOP, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
+            } else {
+                mv((tail.mode != 2 ? 2 : 1) + 2); nm("k_axpy_dot(x_d)");
+                launch(C_XD, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
                        parts_.p, 0);
+            }
             if (desc.f_kind == BZ_F_STENCIL5 && opt.fuse && !lp_g && !slack && !ctx->multi()) {
                 // stencil fast path: {AL gradient at x_d + FB step} and {AL gradient at z + pair + stop norm}
                 // as two passes; same partial sums as the four generic kernels of the first trial
                 for (int sidx = SL_FXD; sidx <= SL_STOP; ++sidx) slot_n[sidx] = grid;
-                launch(C_ALGRAD, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
+                mv(2 + pstreams(false, true, true) + 3);        // x_d, b + parameters ; grad, z, res
+                nm("k_stencil_fb");
+                launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                        (int)SL_GSUM);
-                launch(C_ALGRAD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
+                mv(2 + pstreams(false, true, false) + 5 + 2);   // z, b + parameters, x_d, x, res, res_prev, grad ; s, y
+                nm("k_stencil_update");
+                launch(C_STENCIL_UPD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
                        (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, (T*)nullptr, n, parts_.p,
                        (int)SL_FZ, (int)SL_YS);
@@ -1749,6 +1918,7 @@ template <class T> class Solver final : public SolverBase {
                 ++n_prox;
                 algrad(Z_[zn].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
                 for (int kk = 0; kk < 3; ++kk) slot_n[SL_YS + kk] = grid;
+                mv(8);
                 launch(C_UPDATE, k_update<T>, grid, (const T*)X_[xcur].p, (const T*)X_[xp].p,
                        (const T*)RES_[rn].p, (const T*)RES_[rp].p, (const T*)GX_.p, (const T*)GZ_.p, gamma,
                        S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_YS);
@@ -1800,6 +1970,7 @@ template <class T> class Solver final : public SolverBase {
             if (FBE_new <= threshold || k >= max_bt) break;
             tau = (k >= max_bt - 1) ? T(0) : tau / T(2);
             ++nbt; ++n_bt;
+            mv(3);
             launch(C_MISC, k_blend<T>, grid, (const T*)X_[xd].p, (const T*)Z_[zp].p, tau, T(1) - tau,
                    X_[xb].p, n);
             xcur = xb;
@@ -1812,6 +1983,8 @@ template <class T> class Solver final : public SolverBase {
     launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_, true>, trial_gfc, trial_XV, trial_CC,     \
            (const T*)X_[xp].p, (const T*)nullptr, P, gamma, X_[xb].p, Z_[zn].p, RES_[rn].p, (T*)nullptr,         \
            (T*)nullptr, n, parts_.p, (int)SL_TRIAL)
+                mv((m_at_trial + 1) + 2 + (2 - trial_uni) + 1 + 2);      // the iterates, q, b (mu, mu*y), the trial point ; z, res
+                form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + char('0' + trial_uni) + (trial_nt ? ",NT=1" : ",NT=0") + ",TRIAL=1>";
                 if (trial_nt) { if (trial_uni == 2) BZ_LAUNCH_FCT(true, 2); else if (trial_uni == 1) BZ_LAUNCH_FCT(true, 1); else BZ_LAUNCH_FCT(true, 0); }
                 else { if (trial_uni == 2) BZ_LAUNCH_FCT(false, 2); else if (trial_uni == 1) BZ_LAUNCH_FCT(false, 1); else BZ_LAUNCH_FCT(false, 0); }
 #undef BZ_LAUNCH_FCT
@@ -1848,6 +2021,7 @@ template <class T> class Solver final : public SolverBase {
                 // the accepted pair is not the one the fused trial measured: its Gram products with the
                 // stored pairs come from their own pass
                 for (int k = 0; k < 2 * CM; ++k) slot_n[SL_GU + k] = grid;
+                mv(2 * (int)order.size() + 1);
                 launch(C_DOT, k_gram_pair<T, CM>, grid, compact_vecs(), (const T*)Y_[spare].p, n, parts_.p,
                        (int)SL_GU);
                 gather(SL_GU, 2 * CM, 0u);
@@ -1893,6 +2067,7 @@ template <class T> class Solver final : public SolverBase {
         st->n_fused_iters = n_fused; st->n_lbfgs_skips = n_skips;
         st->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         st->status = std::isnan((double)f_x) ? 2 : ((double)stop_norm_ <= opt.tol ? 0 : 1);
+        st->persist_fallbacks = (int32_t)n_persist_fallbacks_;
     }
 };
 

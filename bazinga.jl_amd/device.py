@@ -16,10 +16,11 @@ class Context:
     """One per process/GPU (bz_ctx).  nranks > 1: x is sharded over the ranks and the
     reductions' partial scalars are all-gathered with RCCL."""
 
-    def __init__(self, device=0, rank=0, nranks=1, comm_id: bytes | None = None):
+    def __init__(self, device=0, rank=0, nranks=1, comm_id: bytes | None = None, runtime_tuning: bool = False):
         lib = L.load()
         o = L.CtxOpts()
         o.device, o.rank, o.nranks = device, rank, nranks
+        o.flags = L.BZ_CTX_RUNTIME_TUNING if runtime_tuning else 0
         self._id = None
         if comm_id is not None and len(comm_id) != 128:
             raise ValueError("comm_id must be the 128-byte id from unique_id() on rank 0")
@@ -40,6 +41,12 @@ class Context:
     def synchronize(self):
         """Drain the solver stream and the device (hipDeviceSynchronize)."""
         L.check(L.load().bz_ctx_synchronize(self._h))
+
+    def comm_nranks(self) -> int:
+        """Ranks the RCCL communicator of this context spans (0 without one)."""
+        out = C.c_int32()
+        L.check(L.load().bz_ctx_comm_nranks(self._h, C.byref(out)))
+        return out.value
 
     def p2p_export(self) -> bytes:
         """This rank's mailbox IPC handle (64 bytes); all-gather them, then p2p_connect."""
@@ -69,6 +76,12 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def runtime_tuning() -> int:
+    """Opt in to the process-wide ROCm runtime settings of bz_runtime_tuning (include/bazinga_hip.h); call before
+    the process's first HIP call.  Returns the mask of variables this call set."""
+    return int(L.load().bz_runtime_tuning())
 
 
 def default_context() -> Context:
@@ -225,6 +238,17 @@ class Problem:
 
     def profile_reset(self):
         L.check(L.load().bz_profile_reset(self._h))
+
+    def profile2(self):
+        """Per kernel category: timed launches / ms / bytes (the launches that carried events), all launches and
+        the bytes they were designed to move since profile_reset, and the template form of the last launch."""
+        out = {}
+        for i, name in enumerate(L.KERNEL_CATEGORIES):
+            r = L.ProfileRec()
+            L.check(L.load().bz_profile_get2(self._h, i, C.byref(r)))
+            out[name] = {"timed_launches": r.timed_launches, "timed_ms": r.timed_ms, "timed_bytes": r.timed_bytes,
+                         "launches": r.launches, "bytes": r.bytes, "form": r.form.decode()}
+        return out
 
     def profile(self):
         out = {}

@@ -85,16 +85,30 @@ typedef struct {
     int32_t device;       /* HIP device ordinal                                      */
     int32_t rank;         /* this rank, 0..nranks-1                                  */
     int32_t nranks;       /* 1 = single GPU; >1 = x sharded, scalars all-gathered    */
-    int32_t reserved;
+    int32_t flags;        /* BZ_CTX_* bits, 0 = none                                 */
     const void* comm_id;  /* 128-byte id from bz_comm_unique_id on rank 0: RCCL communicator
                              (nranks==1 + id: 1-rank communicator, for testing; NULL with
                              nranks>1: p2p mailboxes must be connected instead)        */
 } bz_ctx_opts;
 
+/* bz_ctx_opts.flags */
+#define BZ_CTX_RUNTIME_TUNING 1   /* apply bz_runtime_tuning() before this context's first HIP call         */
+
+/* ROCm runtime settings for a launch-latency-bound host loop (one short kernel chain per PANOC iteration with
+ * the host in the loop): HIP_FORCE_DEV_KERNARG=1 (kernel arguments in device memory) and HSA_ENABLE_INTERRUPT=0
+ * (polled completion signals); worth ~1.5 us per iteration.  They are PROCESS-WIDE environment settings read
+ * when the HIP runtime initialises, so the library never applies them on its own: the host opts in, before the
+ * process's first HIP call, either here or with BZ_CTX_RUNTIME_TUNING on its first bz_ctx_create.  Variables
+ * the process has already set are left alone.  Returns a bit mask: bit 0 HIP_FORCE_DEV_KERNARG was set by
+ * this call, bit 1 HSA_ENABLE_INTERRUPT was.                                                              */
+int  bz_runtime_tuning(void);
+
 int  bz_comm_unique_id(void* id128);                 /* fills 128 bytes (RCCL id)     */
 int  bz_ctx_create(const bz_ctx_opts* opts, bz_ctx** out);
 void bz_ctx_destroy(bz_ctx* ctx);
 int  bz_ctx_synchronize(bz_ctx* ctx);                /* drains the solver stream and the device */
+/* number of ranks the context's RCCL communicator spans (ncclCommCount), 0 without a communicator      */
+int  bz_ctx_comm_nranks(bz_ctx* ctx, int32_t* out);
 /* Peer-to-peer scalar mailboxes (single node, optional; replaces the RCCL all-gather and lets the
  * persistent two-loop kernel run sharded): every rank exports the 64-byte HIP IPC handle of its
  * mailbox, the launcher all-gathers the handles and the device ordinals, every rank connects.      */
@@ -210,7 +224,8 @@ typedef struct {
     int64_t n_lbfgs_skips;    /* updates rejected because <s,y> <= 0                  */
     double  elapsed_s;
     int32_t status;           /* 0 converged, 1 maxit, 2 NaN encountered              */
-    int32_t reserved;
+    int32_t persist_fallbacks;/* times the persistent two-loop kernel's grid barrier timed out (its workgroups
+                                 were not co-resident) and the solve went on with the kernel chain (0 or 1)   */
 } bz_panoc_stats;
 
 /* Multipliers/penalties of the current subproblem:  AugLagUpdate!(alFun, mu, y)
@@ -288,13 +303,30 @@ int bz_eval_lbfgs(bz_problem* p, int32_t m, const void* S, const void* Y,
  *           5 scalar collect, 6 pack + all-gather, 7 misc, 8 k_dot (first two-loop dot),
  *           9 dense GEMV kernels (vector ALU), 10 k_twoloop_persist, 11 k_gemv_t_mfma,
  *           12 k_fused_compact in its steady-state form (history kept as iterates: reads the M+1 last
- *              iterates and the problem data, writes x_d; the other forms of that kernel count under 1).
+ *              iterates and the problem data, writes x_d; the other forms of that kernel count under 1),
+ *           13 k_stencil_fb, 14 k_stencil_update (the two passes of a stencil-f iteration), 15 formation of x_d on
+ *              the unfused paths (k_compact_xd / the two-loop's last axpy).
  * mask: bits 0..15: bit c enables timing of category c (0 = off); bits 16..31: sampling period k
  *       (0/1 = every launch, k = every k-th launch of each enabled category).          */
-#define BZ_NUM_KERNEL_CATEGORIES 13
+#define BZ_NUM_KERNEL_CATEGORIES 16
 int bz_profile_enable(bz_problem* p, int32_t mask);
 int bz_profile_get(bz_problem* p, int32_t category, int64_t* launches, double* total_ms);
 int bz_profile_reset(bz_problem* p);
+/* The same with the bytes each launch is designed to move (its read + write streams x their length x
+ * sizeof(T): what the implemented dataflow must move, not the reference's): over the launches that carried
+ * timing events (timed_*: a sustained rate is timed_bytes / timed_ms) and over EVERY launch of the category
+ * since bz_profile_reset (launches, bytes: moved bytes per iteration).  form: the template form of the
+ * category's last launch (e.g. "k_fused_compact<XR=2,UNI=2,NT=1>"), so that a hardware-counter profile can
+ * be matched to the instantiation that actually ran.                                                      */
+typedef struct {
+    int64_t timed_launches;
+    double  timed_ms;
+    double  timed_bytes;
+    int64_t launches;
+    double  bytes;
+    char    form[96];
+} bz_profile_rec;
+int bz_profile_get2(bz_problem* p, int32_t category, bz_profile_rec* out);
 
 #ifdef __cplusplus
 }

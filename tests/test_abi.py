@@ -34,7 +34,8 @@ def test_struct_layouts_match_the_header(bz):
     """Compile a C program against the header and compare sizeof/offsetof with the ctypes mirrors."""
     L = bz._lib
     structs = {"bz_ctx_opts": L.CtxOpts, "bz_problem_desc": L.ProblemDesc, "bz_panoc_opts": L.PanocOpts,
-               "bz_panoc_stats": L.PanocStats, "bz_alps_opts": L.AlpsOpts, "bz_alps_stats": L.AlpsStats}
+               "bz_panoc_stats": L.PanocStats, "bz_alps_opts": L.AlpsOpts, "bz_alps_stats": L.AlpsStats,
+               "bz_profile_rec": L.ProfileRec}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

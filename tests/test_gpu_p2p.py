@@ -47,10 +47,10 @@ def _worker(rank, world, n_total, persist, conn, compact=False):
         conn.send(("error", repr(e)))
 
 
-def _run_sharded(world, persist, compact=False):
+def _run_sharded(world, persist, compact=False, n_total=N_TOTAL):
     mpc = mp.get_context("spawn")
     pipes = [mpc.Pipe() for _ in range(world)]
-    procs = [mpc.Process(target=_worker, args=(r, world, N_TOTAL, persist, pipes[r][1], compact)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, n_total, persist, pipes[r][1], compact)) for r in range(world)]
     for p in procs:
         p.start()
     handles = [pipes[r][0].recv() for r in range(world)]
@@ -97,6 +97,31 @@ def test_two_ranks_on_one_gpu_match_single_rank(bz, persist, compact):
         assert all(r[6] == 0 and r[7] > 5 * ITERS for r in res)
 
 
+@pytest.mark.timeout(600)
+def test_unequal_shards_take_the_same_two_loop_form(bz):
+    """Shards that straddle the persistent kernel's size threshold (300 032 and 299 967 elements around
+    BZ_PERSIST_MIN_N = 300 000): the ranks must agree on ONE form of the two-loop — the persistent kernel's
+    in-kernel phase exchanges and the kernel chain's mailbox exchanges do not talk to each other — so the
+    decision is exchanged at bz_panoc_begin and the chain is taken by both."""
+    n_total = 599_999
+    res = _run_sharded(2, True, False, n_total)
+    assert [r[2] - r[1] for r in res] == [300_032, 299_967]
+    assert all(r[6] == 0 for r in res), "one rank ran the persistent kernel while the other could not"
+    d = bz.synth.l1_quadratic(n_total)
+    prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                      bz.ClosedSet(bz.IndBox(-1.0, 1.0)), n_total, n_total, np.float64)
+    prob.set_multipliers(np.full(n_total, 0.1), np.sin(np.arange(n_total, dtype=np.float64)))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n_total))
+    for _ in range(ITERS):
+        prob.panoc_step()
+    x1 = prob.panoc_vector("x")
+    prob.close()
+    x = np.concatenate([r[3] for r in res])
+    assert np.max(np.abs(x - x1)) <= 1e-10 * np.max(np.abs(x1))
+    for key in ("gamma", "f_x", "stop_norm", "FBE"):
+        assert res[0][5][key] == res[1][5][key]
+
+
 @pytest.mark.gpu
 def test_bench_launcher_two_ranks_share_one_gpu():
     """The driver's N > 1 launch line (torch.distributed.run, one process per rank) end to end on a one-GPU
@@ -123,6 +148,7 @@ def test_bench_launcher_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["scalar_transport"] == "p2p" and d["config"]["n_per_gpu"] * 2 >= 2_000_000
     assert d["roofline"]["kernel"].startswith("bz::k_fused_compact") and d["cpu_baseline"] is None
+    assert 0.0 < d["roofline"]["frac"] <= 1.0 and 0.0 < d["roofline_iteration"]["frac"] <= d["roofline"]["frac"]
     assert d["solver"]["fused_iterations"] >= 38
 
 

@@ -1185,3 +1185,58 @@ def test_history_as_iterates_and_lazy_z_are_bitwise_neutral(bz, ref, n, iters, s
         assert base[5][2] > 0                            # pairs were skipped: the snapshots had to become pairs again
         assert runs[1][6] > runs[0][6]                   # ... by k_pairs_from_snapshots (category misc)
         assert runs[4][6] > runs[0][6]                   # ... or k_pairs_from_iterates
+
+
+def test_persistent_kernel_barrier_timeout_falls_back_to_the_kernel_chain(bz, ref, monkeypatch):
+    """a grid barrier of the persistent two-loop kernel that cannot complete (workgroups not all
+    resident) must not lose the solve.  BZ_TEST_PERSIST_TIMEOUT=1 makes the barrier miss its target; the bounded
+    polls give up, the iteration is redone with the kernel chain and the persistent form stays off: the iterates
+    are those of a persist=False solve bit for bit, and the statistics say what happened."""
+    n = 400_003
+    d, dev, orc = make_cfg2(bz, ref, n)
+    mu, y, x0 = np.full(n, 0.1), np.cos(np.arange(n, dtype=np.float64)), np.zeros(n)
+    runs = []
+    for sabotage, persist in ((True, True), (False, False)):
+        if sabotage:
+            monkeypatch.setenv("BZ_TEST_PERSIST_TIMEOUT", "1")
+        else:
+            monkeypatch.delenv("BZ_TEST_PERSIST_TIMEOUT", raising=False)
+        prob = bz.Problem(*dev, n, n, np.float64)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist, directions=bz.LBFGS(5, compact=False)).c_opts(), x0)
+        for _ in range(8):
+            prob.panoc_step()
+        runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(), prob.panoc_stats(),
+                     prob.profile2()))
+        prob.close()
+    (xa, za, sa, sta, _), (xb, zb, sb, stb, _) = runs
+    assert sta.persist_fallbacks == 1 and stb.persist_fallbacks == 0
+    assert sa["k"] == sb["k"] == 9 and sta.n_grad == stb.n_grad and sta.n_prox == stb.n_prox
+    assert np.array_equal(xa, xb) and np.array_equal(za, zb)
+    for key in ("gamma", "f_x", "g_z", "stop_norm", "FBE"):
+        assert sa[key] == sb[key]
+
+
+def test_moved_bytes_accounting_of_the_one_pass_kernel(bz, ref):
+    """bz_profile_get2: the bytes a launch is designed to move are its streams x n x 8.  Steady state of the
+    headline family with uniform penalties and y = 0: the six last iterates, q, b in, x_d out = 9 passes."""
+    n = 400_003
+    d, dev, orc = make_cfg2(bz, ref, n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n))
+    for _ in range(30):
+        prob.panoc_step()
+    prob.profile_reset()
+    prob.profile_enable(True)
+    st0 = prob.panoc_stats()
+    for _ in range(10):
+        prob.panoc_step()
+    st1 = prob.panoc_stats()
+    p = prob.profile2()["k_fused_iterates"]
+    prob.close()
+    if st1.n_backtracks == st0.n_backtracks and st1.n_lbfgs_skips == st0.n_lbfgs_skips:
+        assert p["launches"] == 10 and p["timed_launches"] == 10
+        assert p["bytes"] == 10 * 9 * 8 * n and p["timed_bytes"] == p["bytes"]
+        assert p["form"].startswith("k_fused_compact<XR=2,UNI=2,NT=") and p["form"].endswith("TRIAL=0>")
+    assert 0 < p["timed_bytes"] / (p["timed_ms"] * 1e-3) / 8e12 <= 1.0

@@ -1955,27 +1955,41 @@ k_fused_sep(TailArgs<T> a, const T* __restrict__ x, const T* __restrict__ res_pr
         Pack<T> pin = ld(a.in, i0, cnt);
         Pack<T> pv = (a.mode != 2) ? ld(a.v, i0, cnt) : splat(T(0));
         Pack<T> px = ld(x, i0, cnt), prp = ld(res_prev, i0, cnt);
-        Pack<T> pxd, pz, pr, ps, py, pg1, pg2;
+        Pack<T> pxd, pz, pr, ps, py, pg1, pg2, pgt;
+        T f1[PackN<T>::N], p1[PackN<T>::N];
+        // three sweeps over the pack (trial point; gradient + FB step; gradient at z): the pairwise D kinds read the
+        // pair partner's value at each of the three points
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
             T d = tail_elem(a, coef, pin.v[e], pv.v[e]);
-            T xd = px.v[e] + d;
+            pxd.v[e] = px.v[e] + d;
+        }
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            const T xd = pxd.v[e];
             ALOut<T> o1 = al_elem(P.f_kind, P.D_kind, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], pxd.v[e ^ 1] + L.muy.v[e ^ 1], e & 1);
             T t = gamma * o1.grad;
             T y = xd - t;
-            T gterm;
-            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
-            T r = xd - zz;
+            T zz = prox_elem(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], pgt.v[e]);
+            pz.v[e] = zz; pr.v[e] = xd - zz;
+            pg1.v[e] = o1.grad; f1[e] = o1.fterm; p1[e] = o1.pterm;
+        }
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            const T xd = pxd.v[e], zz = pz.v[e], r = pr.v[e];
+            const T gterm = pgt.v[e];
+            ALOut<T> o1;
+            o1.grad = pg1.v[e]; o1.fterm = f1[e]; o1.pterm = p1[e];
             ALOut<T> o2 = al_elem(P.f_kind, P.D_kind, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e]);
+                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], pz.v[e ^ 1] + L.muy.v[e ^ 1], e & 1);
             T s = xd - px.v[e];
             T yy = r - prp.v[e];
             T w = r / gamma;
             w = w - o1.grad;
             w = w + o2.grad;
-            pxd.v[e] = xd; pz.v[e] = zz; pr.v[e] = r; ps.v[e] = s; py.v[e] = yy;
-            pg1.v[e] = o1.grad; pg2.v[e] = o2.grad;
+            ps.v[e] = s; py.v[e] = yy;
+            pg2.v[e] = o2.grad;
             if (e < cnt) {
                 acc[0] += (double)o1.fterm;
                 acc[1] += (double)o1.pterm;
@@ -2027,6 +2041,7 @@ template <int MM> struct CompactCoef {
     // current one when the oldest pair is that of an iteration that halved gamma (y = res_new(gamma/2) -
     // res_prev(gamma), as upstream has it); a halving resets the memory, so no younger iterate can differ.
     double gam0;
+    int uni_rt, trial_rt;      // the kernel's UNI / TRIAL when those template arguments are -1 (family instantiations)
 };
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
@@ -2159,11 +2174,12 @@ __global__ void __launch_bounds__(BLOCK) k_pairs_from_snapshots(SnapVecs<T, MM> 
 // fixed-point residual of one element at a stored iterate:  z = prox_{gamma g}(x - gamma grad L(x)), res = x - z —
 // operation for operation what the fused passes (and k_algrad_elem + k_fbstep) do at a trial point, so
 // re-evaluating it at an iterate the rings still hold gives back the bits of the residual computed then
+// (xpart: the pair partner's iterate value, read by the pairwise D kinds only)
 template <class T>
 __device__ __forceinline__ T resid_elem(int fk, int dk, int gk, T xv, const ElemLoads<T>& L, int e, T gamma, T gl,
-                                        T& zz, bool udiv = false, T rmu = T(0)) {
-    ALOut<T> o = al_elem(fk, dk, xv, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0,
-                         udiv, rmu);
+                                        T& zz, bool udiv = false, T rmu = T(0), T xpart = T(0)) {
+    ALOut<T> o = al_elem(fk, dk, xv, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], L.dlo.v[e], L.dhi.v[e],
+                         xpart + L.muy.v[e ^ 1], e & 1, udiv, rmu);
     T t = gamma * o.grad;
     T y = xv - t;
     T gterm;
@@ -2171,10 +2187,9 @@ __device__ __forceinline__ T resid_elem(int fk, int dk, int gk, T xv, const Elem
     return xv - zz;
 }
 
-// history as iterates, residuals not stored -> history as pairs (headline family: f = DiagQuadratic, g = NormL1,
-// D = Box with scalar bounds): S[i] = XH[i+1] - XH[i], Y[i] = r(XH[i+1]) - r(XH[i]) with r re-evaluated, plus
-// the residual and z of the newest iterate — everything the classic kernels need when an iteration leaves
-// the plain path
+// history as iterates, residuals not stored -> history as pairs (any element-wise family, run-time kinds: this pass
+// is rare): S[i] = XH[i+1] - XH[i], Y[i] = r(XH[i+1]) - r(XH[i]) with r re-evaluated, plus the residual and z of the
+// newest iterate — everything the classic kernels need when an iteration leaves the plain path
 template <class T, int MM>
 __global__ void __launch_bounds__(BLOCK)
 k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T* __restrict__ res_cur,
@@ -2183,9 +2198,7 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T* __restrict__
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;
         ElemLoads<T> L;
-        L.q = ld(P.q, i0, cnt); L.b = ld(P.b, i0, cnt); L.mu = ld(P.mu, i0, cnt); L.muy = ld(P.muy, i0, cnt);
-        L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
-        L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
+        load_params(P, i0, cnt, L, true, true, true);
         Pack<T> xh[MM + 1], rh[MM + 1], pz;
 #pragma unroll
         for (int i = 0; i <= MM; ++i) {
@@ -2194,8 +2207,8 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T* __restrict__
             for (int e = 0; e < PackN<T>::N; ++e) {
                 T zz;
                 const T gi = (T)V.gam[i];
-                rh[i].v[e] = resid_elem<T>((int)BZ_F_DIAG_QUADRATIC, (int)BZ_D_BOX, (int)BZ_G_NORM_L1, xh[i].v[e], L, e,
-                                           gi, gi * P.g_lambda, zz);
+                rh[i].v[e] = resid_elem<T>(P.f_kind, P.D_kind, P.g_kind, xh[i].v[e], L, e, gi, gi * P.g_lambda, zz, false,
+                                           T(0), xh[i].v[e ^ 1]);
                 if (i == MM) pz.v[e] = zz;
             }
         }
@@ -2231,18 +2244,42 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T* __restrict__
 //   TRIAL (XR = 2 only): the trial point is GIVEN in x_d (a tau-blend of the rejected x + d and z: read, not
 //            written) instead of formed as x + d: a backtracked trial is then this one pass too — both
 //            gradients, FB step, pair, its Gram products, p, w, stop norm — with nothing materialised.
-template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, int XR = 0, int UNI = 0, bool TRIAL = false>
+// Oracle family of the iterate-history form (XR = 2), fixed at compile time: the kinds of f, g and D and which of
+// their parameters are vectors (= streams the pass must prefetch).  Every element-wise family the solver lowers
+// has its own instantiation of the one-pass kernel (bz_families_*.hip); the headline family (cfg 2 / cfg 5)
+// additionally fixes UNI and TRIAL at compile time.
+constexpr int FAM_F_ZERO = 0, FAM_F_DIAG = 1;
+constexpr int FAM_G_ZERO = 0, FAM_G_L1 = 1, FAM_G_L1NONNEG = 2, FAM_G_L1BOX = 3, FAM_G_INDBOX = 4, FAM_G_INDBOX_VEC = 5;
+constexpr int FAM_G_COUNT = 6;
+constexpr int FAM_D_ZERO = 0, FAM_D_FREE = 1, FAM_D_BOX = 2, FAM_D_BOX_VEC = 3, FAM_D_PAIRS = 4;
+constexpr int FAM_D_COUNT = 5;
+constexpr int fam_code(int fk, int gk, int dk) { return fk | (gk << 1) | (dk << 4); }
+constexpr int fam_fk(int fam) { return fam & 1; }
+constexpr int fam_gk(int fam) { return (fam >> 1) & 7; }
+constexpr int fam_dk(int fam) { return fam >> 4; }
+constexpr int FAM_HEADLINE = fam_code(FAM_F_DIAG, FAM_G_L1, FAM_D_BOX);
+
+//   UNI / TRIAL = -1: taken at run time from C.uni_rt / C.trial_rt (the family instantiations: a wave-uniform branch
+//   around two loads and one store costs nothing next to a third of the instantiations)
+template <class T, int MM, bool NT, bool SPEC, bool OFF32 = false, int XR = 0, int UNI = 0, int TRIAL = 0,
+          int FAM = FAM_HEADLINE>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x,
                 const T* __restrict__ res_prev, ElemParams<T> P, T gamma, T* __restrict__ x_d,
                 T* __restrict__ z, T* __restrict__ res, T* __restrict__ s_new, T* __restrict__ y_new,
                 int64_t n, double* __restrict__ parts, int slot0) {
-    // SPEC: the headline family (cfg 2 / cfg 5) with everything uniform known at compile time — f =
-    // DiagQuadratic, g = NormL1, D = Box with scalar bounds, full memory: no kind switches, no optional
-    // streams, far fewer live scalar registers (the generic body spills ~300 SGPRs to VGPR lanes)
-    const int fk = SPEC ? (int)BZ_F_DIAG_QUADRATIC : P.f_kind;
-    const int gk = SPEC ? (int)BZ_G_NORM_L1 : P.g_kind;
-    const int dk = SPEC ? (int)BZ_D_BOX : P.D_kind;
+    // SPEC (stored-pair forms): the headline family (cfg 2 / cfg 5) with everything uniform known at compile time —
+    // f = DiagQuadratic, g = NormL1, D = Box with scalar bounds, full memory: no kind switches, no optional
+    // streams, far fewer live scalar registers (the generic body spills ~300 SGPRs to VGPR lanes).
+    // XR = 2: the kinds come from FAM.
+    constexpr bool FAMILY = XR == 2;
+    constexpr int GKC = fam_gk(FAM), DKC = fam_dk(FAM);
+    const int fk = FAMILY ? fam_fk(FAM) : (SPEC ? (int)BZ_F_DIAG_QUADRATIC : P.f_kind);
+    const int gk = FAMILY ? (GKC >= FAM_G_INDBOX ? (int)BZ_G_IND_BOX : GKC) : (SPEC ? (int)BZ_G_NORM_L1 : P.g_kind);
+    const int dk = FAMILY ? (DKC == FAM_D_PAIRS ? P.D_kind : (DKC >= FAM_D_BOX ? (int)BZ_D_BOX : DKC))
+                          : (SPEC ? (int)BZ_D_BOX : P.D_kind);
+    const int uni = UNI >= 0 ? UNI : C.uni_rt;
+    const bool trial = TRIAL >= 0 ? (TRIAL != 0) : (C.trial_rt != 0);
     const int m = SPEC ? MM : V.m;
     T u1[MM], u2h[MM];
     compact_coefs<T, MM>(C, u1, u2h);
@@ -2259,69 +2296,88 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     // on one reciprocal per launch (uniform penalties) or per element
     constexpr bool UDIV = XR == 2 && sizeof(T) == 8;
     T rmu_u = T(0), rgam = T(0);
-    if constexpr (UDIV) { rgam = T(1) / gamma; if constexpr (UNI >= 1) rmu_u = T(1) / P.mu_uniform; }
+    if constexpr (UDIV) { rgam = T(1) / gamma; if (uni >= 1) rmu_u = T(1) / P.mu_uniform; }
     const T gam0 = (T)C.gam0, gl0 = gam0 * P.g_lambda;      // XR = 2: gamma (and gamma*lambda) of the oldest iterate's residual
     constexpr int NS = 10 + 4 * MM + 2;
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-    // XR = 2 reads few enough streams (MM+1 iterates + 2..4 parameter vectors) to keep the NEXT pack's loads in
-    // flight while this pack's ~800 instructions run: a one-deep software pipeline in registers
+    // XR = 2 reads few enough streams (MM+1 iterates + the family's parameter vectors) to keep the NEXT packs' loads in
+    // flight while this pack's ~500-800 instructions run: a software pipeline in registers, two packs deep for the
+    // families with up to 11 streams, one pack deep beyond (the register file holds three stages of 11 packs)
     constexpr bool PIPE = SPEC && OFF32 && XR == 2;
-    struct Stage { Pack<T> q, b, mu, muy, px, ps[MM], xt; };
+    constexpr int NSTREAMS = MM + 1 + (fam_fk(FAM) ? 2 : 0) + (UNI >= 2 ? 0 : (UNI == 1 ? 1 : 2)) + (TRIAL == 0 ? 0 : 1) +
+                             (GKC == FAM_G_L1BOX ? 1 : 0) + (GKC == FAM_G_INDBOX_VEC ? 2 : 0) + (DKC == FAM_D_BOX_VEC ? 2 : 0);
+    constexpr int DEPTH = NSTREAMS <= 11 ? 2 : 1;
+    struct Stage { Pack<T> q, b, mu, muy, px, ps[MM], xt, gu, glo, ghi, dlo, dhi; };
     auto load_stage = [&](Stage& S, unsigned bo) {
         asm volatile("" : "+v"(bo));
-        S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo);
-        if constexpr (UNI < 1) S.mu = ldo<T, NT>(P.mu, bo);
-        if constexpr (UNI < 2) S.muy = ldo<T, NT>(P.muy, bo);
+        if (fk == BZ_F_DIAG_QUADRATIC) { S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo); }
+        if (uni < 1) S.mu = ldo<T, NT>(P.mu, bo);
+        if (uni < 2) S.muy = ldo<T, NT>(P.muy, bo);
         S.px = ldo<T, NT>(x, bo);
-        if constexpr (TRIAL) S.xt = ldo<T, NT>((const T*)x_d, bo);
+        if (trial) S.xt = ldo<T, NT>((const T*)x_d, bo);
 #pragma unroll
         for (int i = 0; i < MM; ++i) S.ps[i] = ldo<T, NT>(V.S[i], bo);
+        if constexpr (GKC == FAM_G_L1BOX) S.gu = ldo<T, NT>(P.g_u, bo);
+        if constexpr (GKC == FAM_G_INDBOX_VEC) {
+            S.glo = P.g_lo_vec ? ldo<T, NT>(P.g_lo_vec, bo) : splat(P.g_lo);
+            S.ghi = P.g_hi_vec ? ldo<T, NT>(P.g_hi_vec, bo) : splat(P.g_hi);
+        }
+        if constexpr (DKC == FAM_D_BOX_VEC) {
+            S.dlo = P.D_lo_vec ? ldo<T, NT>(P.D_lo_vec, bo) : splat(P.D_lo);
+            S.dhi = P.D_hi_vec ? ldo<T, NT>(P.D_hi_vec, bo) : splat(P.D_hi);
+        }
     };
     auto body = [&](const int64_t i0, const auto cnt_, const auto staged_, const Stage& SG) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         // full chunks of a vector shorter than 4 GiB: every stream is (scalar base, one shared 32-bit offset)
         constexpr bool O32 = SPEC && OFF32 && !std::is_integral<std::remove_cv_t<decltype(cnt_)>>::value;
         constexpr bool STAGED = std::remove_cv_t<decltype(staged_)>::value;
+        constexpr int N = PackN<T>::N;
         unsigned bo = (unsigned)(i0 * (int64_t)sizeof(T));
         if constexpr (O32) asm volatile("" : "+v"(bo));      // opaque: no per-stream 64-bit pointer induction variables
         ElemLoads<T> L;
         Pack<T> px, prp, ps[MM], py[MM], d, rmu, pxt;
-        if constexpr (TRIAL) {
+        if (trial) {
             if constexpr (STAGED) pxt = SG.xt; else pxt = ldp<T, NT>((const T*)x_d, i0, cnt);
         }
         if constexpr (STAGED) {
-            L.q = SG.q; L.b = SG.b;
-            if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = SG.mu;
-            if constexpr (UNI >= 2) L.muy = splat(T(0)); else L.muy = SG.muy;
-            L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
-            L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
+            if (fk == BZ_F_DIAG_QUADRATIC) { L.q = SG.q; L.b = SG.b; } else { L.q = splat(T(0)); L.b = splat(T(0)); }
+            if (uni >= 1) L.mu = splat(P.mu_uniform); else L.mu = SG.mu;
+            if (uni >= 2) L.muy = splat(T(0)); else L.muy = SG.muy;
+            if constexpr (DKC == FAM_D_BOX_VEC) { L.dlo = SG.dlo; L.dhi = SG.dhi; } else { L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi); }
+            if constexpr (GKC == FAM_G_L1BOX) L.gu = SG.gu; else L.gu = splat(T(0));
+            if constexpr (GKC == FAM_G_INDBOX_VEC) { L.glo = SG.glo; L.ghi = SG.ghi; } else { L.glo = splat(P.g_lo); L.ghi = splat(P.g_hi); }
             px = SG.px;
 #pragma unroll
             for (int i = 0; i < MM; ++i) ps[i] = SG.ps[i];
-        } else if constexpr (O32) {
+        } else if constexpr (O32 && !FAMILY) {
             L.q = ldo<T, NT>(P.q, bo); L.b = ldo<T, NT>(P.b, bo);
-            if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = ldo<T, NT>(P.mu, bo);
-            if constexpr (UNI >= 2) L.muy = splat(T(0)); else L.muy = ldo<T, NT>(P.muy, bo);
+            L.mu = ldo<T, NT>(P.mu, bo);
+            L.muy = ldo<T, NT>(P.muy, bo);
             L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
             L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
             px = ldo<T, NT>(x, bo);
-            if constexpr (XR != 2) prp = ldo<T, NT>(res_prev, bo);
+            prp = ldo<T, NT>(res_prev, bo);
 #pragma unroll
             for (int i = 0; i < MM; ++i) {
                 ps[i] = ldo<T, NT>(V.S[i], bo);
-                if constexpr (XR != 2) py[i] = ldo<T, NT>(V.Y[i], bo);
+                py[i] = ldo<T, NT>(V.Y[i], bo);
             }
         } else {
-            if (SPEC) {
+            if (SPEC && !FAMILY) {
                 L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
-                if constexpr (UNI >= 1) L.mu = splat(P.mu_uniform); else L.mu = ldp<T, NT>(P.mu, i0, cnt);
-                if constexpr (UNI >= 2) L.muy = splat(T(0)); else L.muy = ldp<T, NT>(P.muy, i0, cnt);
+                L.mu = ldp<T, NT>(P.mu, i0, cnt);
+                L.muy = ldp<T, NT>(P.muy, i0, cnt);
                 L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
                 L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
             } else {
+                // run-time kinds (generic stored-pair body; the ragged last chunk of a family kernel, whose kinds
+                // are those of P by construction)
                 load_params<T, NT>(P, i0, cnt, L, true, true, true);
+                if (FAMILY && uni >= 1) L.mu = splat(P.mu_uniform);
+                if (FAMILY && uni >= 2) L.muy = splat(T(0));
             }
             px = ldp<T, NT>(x, i0, cnt);
             if constexpr (XR != 2) prp = ldp<T, NT>(res_prev, i0, cnt);
@@ -2338,22 +2394,22 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             // iteration that changes them leaves this mode), so again the same bits
             Pack<T> rr[MM + 1];
 #pragma unroll
-            for (int e = 0; e < PackN<T>::N; ++e) {
-                if constexpr (UDIV) rmu.v[e] = (UNI >= 1) ? rmu_u : T(1) / L.mu.v[e];
+            for (int e = 0; e < N; ++e) {
+                if constexpr (UDIV) rmu.v[e] = (uni >= 1) ? rmu_u : T(1) / L.mu.v[e];
 #pragma unroll
                 for (int i = 0; i <= MM; ++i) {
                     T zz;
                     const T gi = (i == 0) ? gam0 : gamma;
                     const T gli = (i == 0) ? gl0 : gl;
                     rr[i].v[e] = resid_elem<T>(fk, dk, gk, (i < MM) ? ps[i].v[e] : px.v[e], L, e, gi, gli, zz, UDIV,
-                                               rmu.v[e]);
+                                               rmu.v[e], (i < MM) ? ps[i].v[e ^ 1] : px.v[e ^ 1]);
                 }
             }
             prp = rr[MM];
 #pragma unroll
             for (int i = 0; i < MM; ++i)
 #pragma unroll
-                for (int e = 0; e < PackN<T>::N; ++e) {
+                for (int e = 0; e < N; ++e) {
                     const T nx = (i + 1 < MM) ? ps[i + 1].v[e] : px.v[e];
                     ps[i].v[e] = nx - ps[i].v[e];
                     py[i].v[e] = rr[i + 1].v[e] - rr[i].v[e];
@@ -2365,39 +2421,47 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
 #pragma unroll
             for (int i = 0; i < MM; ++i)
 #pragma unroll
-                for (int e = 0; e < PackN<T>::N; ++e) {
+                for (int e = 0; e < N; ++e) {
                     const T nx = (i + 1 < MM) ? ps[i + 1].v[e] : px.v[e];
                     const T nr = (i + 1 < MM) ? py[i + 1].v[e] : prp.v[e];
                     ps[i].v[e] = nx - ps[i].v[e];
                     py[i].v[e] = nr - py[i].v[e];
                 }
         }
-        if constexpr (!TRIAL) compact_d<T, MM>(m, H0, u1, u2h, prp, ps, py, d);
-        Pack<T> pxd, pz, pr, pss, pyy;
+        if (!trial) compact_d<T, MM>(m, H0, u1, u2h, prp, ps, py, d);
+        // the trial point, then gradient + forward-backward step, then the gradient at z: three sweeps over the
+        // pack's elements, because the pairwise D kinds read the pair partner's value at each of the three points
+        Pack<T> pxd, pz, pr, pss, pyy, pg1, pgt;
 #pragma unroll
-        for (int e = 0; e < PackN<T>::N; ++e) {
-            T xd;
-            if constexpr (TRIAL) xd = pxt.v[e]; else xd = px.v[e] + d.v[e];
-            ALOut<T> o1 = al_elem(fk, dk, xd, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu.v[e]);
+        for (int e = 0; e < N; ++e) pxd.v[e] = trial ? pxt.v[e] : px.v[e] + d.v[e];
+        T f1[N], p1[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const T xd = pxd.v[e];
+            ALOut<T> o1 = al_elem(fk, dk, xd, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], L.dlo.v[e], L.dhi.v[e],
+                                  pxd.v[e ^ 1] + L.muy.v[e ^ 1], e & 1, UDIV, rmu.v[e]);
             T t = gamma * o1.grad;
             T y = xd - t;
-            T gterm;
-            T zz = prox_elem(gk, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
-            T r = xd - zz;
-            ALOut<T> o2 = al_elem(fk, dk, zz, L.q.v[e], L.b.v[e], L.mu.v[e],
-                                  L.muy.v[e], L.dlo.v[e], L.dhi.v[e], T(0), 0, UDIV, rmu.v[e]);
+            T zz = prox_elem(gk, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], pgt.v[e]);
+            pz.v[e] = zz; pr.v[e] = xd - zz;
+            pg1.v[e] = o1.grad; f1[e] = o1.fterm; p1[e] = o1.pterm;
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const T xd = pxd.v[e], zz = pz.v[e], r = pr.v[e];
+            ALOut<T> o2 = al_elem(fk, dk, zz, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], L.dlo.v[e], L.dhi.v[e],
+                                  pz.v[e ^ 1] + L.muy.v[e ^ 1], e & 1, UDIV, rmu.v[e]);
             T sv = xd - px.v[e];
             T yy = r - prp.v[e];
             T w = UDIV ? div_u(r, gamma, rgam) : r / gamma;
-            w = w - o1.grad;
+            w = w - pg1.v[e];
             w = w + o2.grad;
-            pxd.v[e] = xd; pz.v[e] = zz; pr.v[e] = r; pss.v[e] = sv; pyy.v[e] = yy;
+            pss.v[e] = sv; pyy.v[e] = yy;
             if (e < cnt) {
-                acc[0] += (double)o1.fterm;
-                acc[1] += (double)o1.pterm;
-                acc[2] += (double)gterm;
-                acc[3] += (double)(o1.grad * r);
+                acc[0] += (double)f1[e];
+                acc[1] += (double)p1[e];
+                acc[2] += (double)pgt.v[e];
+                acc[3] += (double)(pg1.v[e] * r);
                 acc[4] += (double)(r * r);
                 acc[5] += (double)o2.fterm;
                 acc[6] += (double)o2.pterm;
@@ -2422,12 +2486,12 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         }
         if constexpr (O32) {
-            if constexpr (!TRIAL) sto<T, NT>(x_d, bo, pxd);
+            if (!trial) sto<T, NT>(x_d, bo, pxd);
             if (z) sto<T, NT>(z, bo, pz);
             if (XR != 2 || res) sto<T, NT>(res, bo, pr);
             if constexpr (XR == 0) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }
         } else {
-            if constexpr (!TRIAL) stp<T, NT>(x_d, i0, cnt, pxd);
+            if (!trial) stp<T, NT>(x_d, i0, cnt, pxd);
             if (z) stp<T, NT>(z, i0, cnt, pz);
             if (XR != 2 || res) stp<T, NT>(res, i0, cnt, pr);
             if constexpr (XR == 0) {
@@ -2437,26 +2501,37 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         }
     };
     if constexpr (PIPE) {
-        // the chunk -> thread map of bz_for_chunks, with the loads of chunk c + stride issued before chunk c is
+        // the chunk -> thread map of bz_for_chunks, with the loads of the next chunks issued before chunk c is
         // consumed (past the end a thread re-requests the last full chunk: no branch, nothing out of bounds)
         constexpr int N = PackN<T>::N;
         const int64_t nfull = n / N;
         const int64_t stride = (int64_t)gridDim.x * BLOCK;
         int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-        // two packs ahead: with one, a wave has 8..10 KB in flight and the pass is bound by latency x concurrency
-        // (three stages used in rotation, the loop unrolled by three: no register copies between iterations)
-        Stage sa, sb, sc;
         auto clampc = [&](int64_t k) { return k < nfull ? k : (nfull - 1); };
         auto fetch = [&](Stage& S, int64_t k) { load_stage(S, (unsigned)(clampc(k) * N * (int64_t)sizeof(T))); };
         auto use = [&](const Stage& S, int64_t k) { body(k * N, std::integral_constant<int, N>{}, std::true_type{}, S); };
-        if (c < nfull) { fetch(sa, c); fetch(sb, c + stride); }
-        for (;;) {
-            if (c >= nfull) break;
-            fetch(sc, c + 2 * stride); use(sa, c); c += stride;
-            if (c >= nfull) break;
-            fetch(sa, c + 2 * stride); use(sb, c); c += stride;
-            if (c >= nfull) break;
-            fetch(sb, c + 2 * stride); use(sc, c); c += stride;
+        Stage sa, sb;
+        if constexpr (DEPTH == 2) {
+            // two packs ahead: with one, a wave has 8..10 KB in flight and the pass is bound by latency x concurrency
+            // (three stages used in rotation, the loop unrolled by three: no register copies between iterations)
+            Stage sc;
+            if (c < nfull) { fetch(sa, c); fetch(sb, c + stride); }
+            for (;;) {
+                if (c >= nfull) break;
+                fetch(sc, c + 2 * stride); use(sa, c); c += stride;
+                if (c >= nfull) break;
+                fetch(sa, c + 2 * stride); use(sb, c); c += stride;
+                if (c >= nfull) break;
+                fetch(sb, c + 2 * stride); use(sc, c); c += stride;
+            }
+        } else {
+            if (c < nfull) fetch(sa, c);
+            for (;;) {
+                if (c >= nfull) break;
+                fetch(sb, c + stride); use(sa, c); c += stride;
+                if (c >= nfull) break;
+                fetch(sa, c + stride); use(sb, c); c += stride;
+            }
         }
         if (c == nfull && nfull * N < n) body(c * N, (int)(n - nfull * N), std::false_type{}, sa);
     } else {

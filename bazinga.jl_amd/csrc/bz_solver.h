@@ -105,6 +105,13 @@ enum Slot : int {
 constexpr int MAX_MEM = 16;
 constexpr int CM = 5;            // capacity of the compact L-BFGS form (pairs)
 
+// the one-pass iteration kernel of an oracle family (k_fused_compact<T, CM, NT, true, true, 2, -1, -1, FAM>)
+template <class T>
+using FusedFn = void (*)(CompactVecs<T, CM>, CompactCoef<CM>, const T*, const T*, ElemParams<T>, T, T*, T*, T*, T*, T*,
+                         int64_t, double*, int);
+template <class T, int DK> FusedFn<T> family_kernel_dk(int fam, bool nt);      // bz_families_dk<DK>.hip
+template <class T> FusedFn<T> family_kernel(int fam, bool nt);
+
 struct SolverBase {
     virtual ~SolverBase() = default;
     virtual void set_multipliers(const void* mu, const void* y) = 0;

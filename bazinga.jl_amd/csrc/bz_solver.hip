@@ -641,6 +641,7 @@ template <class T> class Solver final : public SolverBase {
     int xr_run_ = 0;             // consecutive plain, pair-inserting iterations so far
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
+    int famrt_env_ = 0;          // BZ_FAMRT=1: the headline family through its family-table instantiation (run-time UNI / TRIAL)
     bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
     bool rh_stale_ = false;      // ... and the residual ring was not written either during this run
     double gring_[NXR] = {0};    // the gamma the residual of each iterate in the ring was (or would be) formed with
@@ -1236,7 +1237,7 @@ template <class T> class Solver final : public SolverBase {
         // in D, alps.jl:97 scales them alike, and y0 = 0 holds through the first subproblem — the longest one.
         uni_ = 0;
         const int uni_env = std::getenv("BZ_UNI") ? std::atoi(std::getenv("BZ_UNI")) : 2;      // (tests toggle it)
-        const bool probe = uni_env && fused_family();
+        const bool probe = uni_env && fused_family() >= 0;
         for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
         mv(3 + (safeguard ? 1 : 0), ny);
         launch(C_MISC, k_muy<T>, grid_y, (const T*)mu_.p, ymul_.p, muy_.p, ny, parts_.p, (int)SL_OUTER,
@@ -1264,10 +1265,31 @@ template <class T> class Solver final : public SolverBase {
             P.mu_uniform = (T)u[0];
         }
     }
-    // the oracle family the specialised one-pass kernel serves (see step())
-    bool fused_family() const {
-        return desc.c_kind == BZ_C_IDENTITY && !slack && desc.f_kind == BZ_F_DIAG_QUADRATIC &&
-               desc.g_kind == BZ_G_NORM_L1 && desc.D_kind == BZ_D_BOX && !P.D_lo_vec && !P.D_hi_vec && ny == n;
+    // the oracle family of the iterate-history one-pass kernel (fam_code, bz_kernels.h), or -1: c = Identity, an
+    // element-wise f, any element-wise g but the Newton / L0 kinds, any D
+    int fused_family() const {
+        if (desc.c_kind != BZ_C_IDENTITY || slack || ny != n || lp_g) return -1;
+        int fk, gk, dk;
+        switch (desc.f_kind) {
+        case BZ_F_ZERO: fk = FAM_F_ZERO; break;
+        case BZ_F_DIAG_QUADRATIC: fk = FAM_F_DIAG; break;
+        default: return -1;
+        }
+        switch (desc.g_kind) {
+        case BZ_G_ZERO: gk = FAM_G_ZERO; break;
+        case BZ_G_NORM_L1: gk = FAM_G_L1; break;
+        case BZ_G_NORM_L1_NONNEG: gk = FAM_G_L1NONNEG; break;
+        case BZ_G_NORM_L1_BOX: gk = FAM_G_L1BOX; break;
+        case BZ_G_IND_BOX: gk = (P.g_lo_vec || P.g_hi_vec) ? FAM_G_INDBOX_VEC : FAM_G_INDBOX; break;
+        default: return -1;
+        }
+        switch (desc.D_kind) {
+        case BZ_D_ZERO: dk = FAM_D_ZERO; break;
+        case BZ_D_FREE: dk = FAM_D_FREE; break;
+        case BZ_D_BOX: dk = (P.D_lo_vec || P.D_hi_vec) ? FAM_D_BOX_VEC : FAM_D_BOX; break;
+        default: dk = FAM_D_PAIRS; break;
+        }
+        return fam_code(fk, gk, dk);
     }
     int uni_ = 0;
 
@@ -1535,7 +1557,7 @@ template <class T> class Solver final : public SolverBase {
         if (o.lbfgs_compact < 0 || o.lbfgs_compact > 2) throw Error(BZ_ERR_ARG, "lbfgs_compact must be 0, 1 or 2 (auto)");
         if (o.lbfgs_compact == 1 && M > CM) throw Error(BZ_ERR_ARG, "lbfgs_compact supports lbfgs_memory <= 5");
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
-        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack && desc.D_kind <= BZ_D_BOX &&
+        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
         // auto: the compact representation where it makes the whole iteration one pass (the fused separable
         // path, memory within its capacity), the two-loop recursion everywhere else
@@ -1570,6 +1592,7 @@ template <class T> class Solver final : public SolverBase {
         trialfuse_env_ = std::getenv("BZ_TRIALFUSE") ? std::atoi(std::getenv("BZ_TRIALFUSE")) : 1;
         fused_begin_env_ = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
+        famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
         const T eps = std::numeric_limits<T>::epsilon();
@@ -1714,7 +1737,7 @@ template <class T> class Solver final : public SolverBase {
         // direction d = H(-res): all but the last axpy
         // (headline family: the one-pass kernel also serves an EMPTY memory — d = H0 (-res), all coefficients zero —
         // so the first iteration of a solve is a 3..5-stream pass too instead of k_fused_sep's 12)
-        const bool use_compact = compact_ok && (!order.empty() || (fused_ok && fused_family()));
+        const bool use_compact = compact_ok && (!order.empty() || (fused_ok && fused_family() >= 0));
         const bool use_persist = persist_ok && !order.empty() && !use_compact;
         CompactVecs<T, CM> CV;
         CompactCoef<CM> CC;
@@ -1737,7 +1760,8 @@ template <class T> class Solver final : public SolverBase {
         // a backtracked trial point can go through the one-pass kernel too ("trial given" variant) when this
         // iteration's first trial did: what that launch used is kept here
         bool trial_ok = false, trial_nt = false;
-        int trial_uni = 0, trial_gfc = 0;
+        int trial_uni = 0, trial_gfc = 0, trial_fam = -1;
+        bool trial_table = false;
         CompactVecs<T, CM> trial_XV;
         CompactCoef<CM> trial_CC;
         double sep_p = 0.0, sep_w = 0.0;      // <s_new, -res>, <y_new, -res> as measured by a k_fused_sep trial
@@ -1752,9 +1776,9 @@ template <class T> class Solver final : public SolverBase {
             static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
             // headline family with everything uniform fixed at compile time (see the kernel)
             static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
-            const bool family = spec_env && desc.f_kind == BZ_F_DIAG_QUADRATIC && desc.g_kind == BZ_G_NORM_L1 &&
-                                desc.D_kind == BZ_D_BOX && !P.D_lo_vec && !P.D_hi_vec;
-            const bool spec = family && CV.m == CM;
+            const int fam = fused_family();
+            const bool headline = spec_env && fam == FAM_HEADLINE;
+            const bool spec = headline && CV.m == CM;
 #define BZ_LAUNCH_FC(NT_, SPEC_)                                                                                  \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, SPEC_>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
@@ -1774,9 +1798,9 @@ template <class T> class Solver final : public SolverBase {
             // with a partial memory (the absent pairs are x - x = 0 with zero coefficients)
             const int m_now = (int)order.size();
             int xr = 0;
-            if (xr_env_ && small && family && xr_run_ >= m_now) {
+            if (xr_env_ && small && fam >= 0 && xr_run_ >= m_now) {
                 if (xr_env_ >= 2) xr = 2;
-                else if (m_now == CM && !rh_stale_) xr = 1;
+                else if (headline && m_now == CM && !rh_stale_) xr = 1;
                 // (only the oldest stored iterate may carry another gamma — see CompactCoef::gam0)
                 for (int i = 1; i < m_now; ++i)
                     if (gring_[(xc - m_now + i + NXR) % NXR] != (double)gamma) xr = 0;
@@ -1791,8 +1815,9 @@ template <class T> class Solver final : public SolverBase {
             // forms then agree to rounding, not bit for bit — BZ_GFC pins one grid for all of them.)
             if (xr == 2 && gfc_env <= 0) gfc = std::min(grid, std::max(1, num_cus));
             for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
-            // (the vectors this pass touches: history + x_d + z + q, b, mu, mu*y (+ res, s, y))
-            const int nvec = (xr == 2 ? CM + 6 - uni : 2 * CM + 9) + (zstore ? 1 : 0);
+            // (the vectors this pass touches: history + x_d + z + the parameter vectors (+ res, s, y))
+            const int xr2_streams = (m_now + 1) + pstreams(true, true, true) - (uni >= 1 ? 1 : 0) - (uni >= 2 ? 1 : 0) + 1;
+            const int nvec = (xr == 2 ? xr2_streams : 2 * CM + 5 + pstreams(true, true, true)) + (zstore ? 1 : 0);
             const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * nvec > 340e6;
             if (xr == 2) {
                 CompactVecs<T, CM> XV;
@@ -1807,15 +1832,29 @@ template <class T> class Solver final : public SolverBase {
     launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,        \
            (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p,     \
            (int)SL_TRIAL)
-                // streams: the m_now + 1 distinct iterates (x among them), q, b, mu / mu*y unless passed as numbers; x_d (z)
-                mv((m_now + 1) + 2 + (2 - uni) + 1 + (zstore ? 1 : 0));
-                form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + char('0' + uni) + (nt ? ",NT=1" : ",NT=0") + ",TRIAL=0>";
-                if (nt) { if (uni == 2) BZ_LAUNCH_FC2(true, 2); else if (uni == 1) BZ_LAUNCH_FC2(true, 1); else BZ_LAUNCH_FC2(true, 0); }
-                else { if (uni == 2) BZ_LAUNCH_FC2(false, 2); else if (uni == 1) BZ_LAUNCH_FC2(false, 1); else BZ_LAUNCH_FC2(false, 0); }
+                // streams: the m_now + 1 distinct iterates (x among them), the family's parameter vectors (mu / mu*y
+                // unless passed as numbers); x_d (z)
+                mv(xr2_streams + (zstore ? 1 : 0));
+                const bool table = !headline || famrt_env_;
+                if (table) {
+                    // every other element-wise family: its own instantiation (kinds and streams fixed at compile time),
+                    // UNI / TRIAL as run-time arguments
+                    CC.uni_rt = uni; CC.trial_rt = 0;
+                    FusedFn<T> fn = family_kernel<T>(fam, nt);
+                    if (!fn) throw Error(BZ_ERR_STATE, "no one-pass kernel instantiation for this oracle family");
+                    form_[C_FUSED_IT] = "k_fused_compact<XR=2,UNI=-1,NT=" + std::to_string(nt ? 1 : 0) + ",TRIAL=-1,FAM=" + std::to_string(fam) + ">";
+                    launch(C_FUSED_IT, fn, gfc, XV, CC, (const T*)X_[xp].p, (const T*)nullptr, P, gamma, X_[xd].p, zstore,
+                           (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p, (int)SL_TRIAL);
+                } else {
+                    form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + char('0' + uni) + (nt ? ",NT=1" : ",NT=0") + ",TRIAL=0>";
+                    if (nt) { if (uni == 2) BZ_LAUNCH_FC2(true, 2); else if (uni == 1) BZ_LAUNCH_FC2(true, 1); else BZ_LAUNCH_FC2(true, 0); }
+                    else { if (uni == 2) BZ_LAUNCH_FC2(false, 2); else if (uni == 1) BZ_LAUNCH_FC2(false, 1); else BZ_LAUNCH_FC2(false, 0); }
+                }
 #undef BZ_LAUNCH_FC2
                 sy_stale_ = true; rh_stale_ = true; res_skipped = true;
                 const int tf_now = trialfuse_env_;
                 trial_ok = tf_now != 0; trial_nt = nt; trial_uni = uni; trial_gfc = gfc; trial_XV = XV; trial_CC = CC;
+                trial_table = table; trial_fam = fam;
             } else if (xr) {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
@@ -1842,13 +1881,13 @@ template <class T> class Solver final : public SolverBase {
                 // stored pairs: res, S[m], Y[m], x + the parameter vectors ; x_d, res, s_new, y_new (z)
                 mv(2 + 2 * CV.m + pstreams(true, true, true) + 4 + (zstore ? 1 : 0));
                 form_[C_FUSED] = std::string("k_fused_compact<XR=0") + (spec ? ",SPEC=1" : ",SPEC=0") + (nt ? ",NT=1>" : ",NT=0>");
+                if (off32 && nt) BZ_LAUNCH_FC3(true);
+                else if (off32) BZ_LAUNCH_FC3(false);
+                else if (nt && spec) BZ_LAUNCH_FC(true, true);
+                else if (nt) BZ_LAUNCH_FC(true, false);
+                else if (spec) BZ_LAUNCH_FC(false, true);
+                else BZ_LAUNCH_FC(false, false);
             }
-            if (off32 && nt) BZ_LAUNCH_FC3(true);
-            else if (off32) BZ_LAUNCH_FC3(false);
-            else if (nt && spec) BZ_LAUNCH_FC(true, true);
-            else if (nt) BZ_LAUNCH_FC(true, false);
-            else if (spec) BZ_LAUNCH_FC(false, true);
-            else BZ_LAUNCH_FC(false, false);
 #undef BZ_LAUNCH_FC3
 #undef BZ_LAUNCH_FC
             if (ctx->p2p_on) {
@@ -1980,13 +2019,22 @@ template <class T> class Solver final : public SolverBase {
                 // of iterates; z and res of the new state are stored (Z_[zn], RES_[rn])
                 for (int kk = 0; kk < NFC; ++kk) slot_n[SL_TRIAL + kk] = trial_gfc;
 #define BZ_LAUNCH_FCT(NT_, UNI_)                                                                                  \
-    launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_, true>, trial_gfc, trial_XV, trial_CC,     \
+    launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_, 1>, trial_gfc, trial_XV, trial_CC,     \
            (const T*)X_[xp].p, (const T*)nullptr, P, gamma, X_[xb].p, Z_[zn].p, RES_[rn].p, (T*)nullptr,         \
            (T*)nullptr, n, parts_.p, (int)SL_TRIAL)
-                mv((m_at_trial + 1) + 2 + (2 - trial_uni) + 1 + 2);      // the iterates, q, b (mu, mu*y), the trial point ; z, res
+                // the iterates, the parameter vectors (mu, mu*y unless numbers), the trial point ; z, res
+                mv((m_at_trial + 1) + pstreams(true, true, true) - (trial_uni >= 1 ? 1 : 0) - (trial_uni >= 2 ? 1 : 0) + 1 + 2);
+                if (trial_table) {
+                    trial_CC.uni_rt = trial_uni; trial_CC.trial_rt = 1;
+                    FusedFn<T> fn = family_kernel<T>(trial_fam, trial_nt);
+                    form_[C_FUSED_IT] = "k_fused_compact<XR=2,UNI=-1,NT=" + std::to_string(trial_nt ? 1 : 0) + ",TRIAL=-1,FAM=" + std::to_string(trial_fam) + ">";
+                    launch(C_FUSED_IT, fn, trial_gfc, trial_XV, trial_CC, (const T*)X_[xp].p, (const T*)nullptr, P, gamma,
+                           X_[xb].p, Z_[zn].p, RES_[rn].p, (T*)nullptr, (T*)nullptr, n, parts_.p, (int)SL_TRIAL);
+                } else {
                 form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + char('0' + trial_uni) + (trial_nt ? ",NT=1" : ",NT=0") + ",TRIAL=1>";
                 if (trial_nt) { if (trial_uni == 2) BZ_LAUNCH_FCT(true, 2); else if (trial_uni == 1) BZ_LAUNCH_FCT(true, 1); else BZ_LAUNCH_FCT(true, 0); }
                 else { if (trial_uni == 2) BZ_LAUNCH_FCT(false, 2); else if (trial_uni == 1) BZ_LAUNCH_FCT(false, 1); else BZ_LAUNCH_FCT(false, 0); }
+                }
 #undef BZ_LAUNCH_FCT
                 if (ctx->p2p_on) {
                     tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
@@ -2070,6 +2118,19 @@ template <class T> class Solver final : public SolverBase {
         st->persist_fallbacks = (int32_t)n_persist_fallbacks_;
     }
 };
+
+// one-pass kernel of an oracle family: the instantiations live in bz_families_dk*.hip (one file per D class, so that
+// they compile in parallel)
+template <class T> FusedFn<T> family_kernel(int fam, bool nt) {
+    switch (fam_dk(fam)) {
+    case FAM_D_ZERO: return family_kernel_dk<T, FAM_D_ZERO>(fam, nt);
+    case FAM_D_FREE: return family_kernel_dk<T, FAM_D_FREE>(fam, nt);
+    case FAM_D_BOX: return family_kernel_dk<T, FAM_D_BOX>(fam, nt);
+    case FAM_D_BOX_VEC: return family_kernel_dk<T, FAM_D_BOX_VEC>(fam, nt);
+    case FAM_D_PAIRS: return family_kernel_dk<T, FAM_D_PAIRS>(fam, nt);
+    default: return nullptr;
+    }
+}
 
 SolverBase* make_solver(Ctx* ctx, const bz_problem_desc& d) {
     if (d.dtype == BZ_F64) return new Solver<double>(ctx, d);

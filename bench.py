@@ -111,6 +111,34 @@ def algorithmic_bytes_per_iter(n, w=8, m=M_LBFGS, n_al=2, n_fb=1, p_al=6):
     return w * n * ((8 * m + 1) + p_al * n_al + 4 * n_fb + 8)
 
 
+def note(msg):
+    """progress line on stderr (a long silent run looks hung to the GPU box's watchdog)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus():
+    """(threads to use, affinity count, cgroup quota in CPUs or None): the GPU box lists every host CPU in the
+    affinity mask but its container is throttled to a CPU quota — more runnable threads than the quota only makes
+    the OpenMP barriers spin against the throttle."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            a, b = fh.read().split()
+        if a != "max":
+            quota = float(a) / float(b)
+    except Exception:      # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:      # noqa: BLE001
+            pass
+    use = aff if quota is None else max(1, min(aff, int(quota)))
+    return use, aff, quota
+
+
 def cpu_baseline(n, states):
     """The oracle's plain-C port (oracle/c/bz_oracle.c: one loop per Julia broadcast, no fusion) timed on
     this box's host cores on the same workload, bounded sample.  Two legs: single-threaded
@@ -121,6 +149,7 @@ def cpu_baseline(n, states):
     mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
     kw = dict(lam=d["lam"], D="box", D_lo=d["lo"], D_hi=d["hi"], minimum_gamma=float(np.finfo(float).eps))
     c_port.load()
+    note(f"cpu baseline, single-thread leg: {states} states at n={n}")
     t0 = time.perf_counter()
     c_port.panoc_run(d["q"], d["b"], mu, y, x0, states, **kw)
     dt = time.perf_counter() - t0
@@ -131,8 +160,12 @@ def cpu_baseline(n, states):
            # the real reference would be timed here if the box had Julia + ProximalAlgorithms
            "julia_on_box": __import__("shutil").which("julia") is not None}
     try:
-        threads = int(os.environ.get("BZ_BENCH_CPU_THREADS", "0")) or len(os.sched_getaffinity(0))
+        use, aff, quota = usable_cpus()
+        threads = int(os.environ.get("BZ_BENCH_CPU_THREADS", "0")) or use
+        out["cgroup_cpu_quota"] = quota
         os.environ["OMP_NUM_THREADS"] = str(threads)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        note(f"cpu baseline, all-cores leg: {threads} threads (affinity {aff}, cgroup quota {quota})")
         c_port.load(omp=True)
         st2 = 4 * states - 3
         c_port.panoc_run(d["q"], d["b"], mu, y, x0, 3, omp=True, **kw)          # thread pool + page warm-up
@@ -141,7 +174,8 @@ def cpu_baseline(n, states):
         dt2 = time.perf_counter() - t0
         out["all_cores"] = {"value": round((st2 - 1) / dt2, 4), "unit": "iterations/s", "cores": threads,
                             "sample": f"first {st2 - 1} iterations, same loops under `omp parallel for`, "
-                                      f"{threads} threads, {dt2:.1f} s"}
+                                      f"{threads} threads = every CPU this container may use (affinity {aff}, "
+                                      f"cgroup quota {quota}), {dt2:.1f} s"}
     except Exception as e:      # noqa: BLE001  (no OpenMP build on this box: the single-thread leg stands)
         out["all_cores"] = {"value": None, "note": repr(e)[:200]}
     return out
@@ -371,6 +405,7 @@ def side_workload(args):
         prob.panoc_begin(popts, x0)
         prob.panoc_steps(args.warmup)
 
+    note(f"{args.workload}: warm-up {args.warmup} + {args.steps} timed iterations")
     fresh()
     prob.profile_reset()
     prob.profile_enable(True, period=int(os.environ.get("BZ_BENCH_PERIOD", "2")))
@@ -391,6 +426,7 @@ def side_workload(args):
     rep = repeat_blocks(elapsed, args.steps, lambda: (fresh(), run_block(prob, args.steps, None))[1])
     cpu = None
     if not args.no_cpu_baseline:
+        note(f"{args.workload}: cpu baseline on the numpy oracle")
         from oracle import bazinga_ref as ref
         cpu = cpu_baseline_oracle(args.workload, oracles(ref), n, ny, dt, mu, y, x0, mg)
     out = {
@@ -659,8 +695,10 @@ def main():
                 "prof": prof, "prof2": prob.profile2(), "prof_warm": prof_warm, "dom": dom, "restarts": restarts,
                 "carry": carry}
 
+    note(f"rank {rank}: timed run, {args.warmup} + {args.steps} iterations, n_local={nl}, transport={transport}")
     prob = make_problem(ctx)
     R = timed_run(prob, args.steps, args.warmup)
+    note(f"rank {rank}: timed run done" + (f": FAILED {R['failed']}" if "failed" in R else f": {args.steps / R['elapsed']:.1f} it/s"))
     if "failed" in R and transport == "p2p" and ctx_rccl is not None:
         # every rank sees the same verdict (sync carries it): fall back to the RCCL transport together
         p2p_note = f"p2p failed in the timed run ({R['failed']}); RCCL timed instead"
@@ -706,6 +744,7 @@ def main():
     #              SURVEY §8(d)
     extras = {}
     if world == 1 and not args.no_extras:
+        note("extras: two-loop form and outer iteration 3")
         if compact:
             popts_tl = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),
                                     fuse=not args.no_fuse, directions=bz.LBFGS(M_LBFGS, compact=False)).c_opts()

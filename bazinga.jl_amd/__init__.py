@@ -6,7 +6,7 @@ importable name onto this directory, whose name is not a valid Python identifier
 from . import _lib, synth
 from ._lib import BazingaHipError
 from .device import Context, Problem, default_context, runtime_tuning, set_default_context, shard_bounds
-from .oracles import (ClosedSet, DenseAffine, DiagQuadratic, FreeSet, IdentityFunction, IndBox, IndFree, IndicatorSet,
+from .oracles import (CallbackError, ClosedSet, DenseAffine, DiagQuadratic, FreeSet, IdentityFunction, IndBox, IndFree, IndicatorSet,
                       LeastSquares, NormL0Box, NormLpPowerBox, NormLpPowerNonneg, Quadratic,
                       NormL1, NormL1Box, NormL1Nonneg, Stencil5ptQuadratic, UnsupportedOracle, Zero, ZeroSet,
                       PairwiseSet, VanishingConstraintPairs, ComplementarityPairs, EitherOrPairs, XorPairs)

@@ -20,6 +20,13 @@ BZ_G_NORM_LP_NONNEG, BZ_G_NORM_LP_BOX = 6, 7
 BZ_C_IDENTITY, BZ_C_DENSE_AFFINE = 0, 1
 BZ_D_ZERO, BZ_D_FREE, BZ_D_BOX = 0, 1, 2
 BZ_D_VC_PAIRS, BZ_D_CC_PAIRS, BZ_D_EITHEROR_PAIRS, BZ_D_XOR_PAIRS = 3, 4, 5, 6
+BZ_F_CALLBACK, BZ_G_CALLBACK, BZ_C_CALLBACK, BZ_D_CALLBACK = 5, 8, 2, 7
+# host-callback oracle protocol (include/bazinga_hip.h)
+F_GRADIENT_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+G_PROX_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64)
+C_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64)
+C_JTPROD_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64)
+D_PROJ_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 NUM_KERNEL_CATEGORIES = 16
 KERNEL_CATEGORIES = ("k_axpy_dot", "k_fused_sep", "al_gradient", "fb_step",
                      "lbfgs_update", "collect", "all_gather", "misc", "k_dot", "gemv", "k_twoloop_persist", "k_gemv_t_mfma",
@@ -50,6 +57,8 @@ class ProblemDesc(C.Structure):
         ("g_lo_vec", C.c_void_p), ("g_hi_vec", C.c_void_p),
         ("c_A", C.c_void_p), ("c_b", C.c_void_p),
         ("D_lo", C.c_double), ("D_hi", C.c_double), ("D_lo_vec", C.c_void_p), ("D_hi_vec", C.c_void_p),
+        ("cb_user", C.c_void_p), ("cb_f_gradient", F_GRADIENT_FN), ("cb_g_prox", G_PROX_FN),
+        ("cb_c_eval", C_EVAL_FN), ("cb_c_jtprod", C_JTPROD_FN), ("cb_D_proj", D_PROJ_FN),
     ]
 
 

@@ -115,7 +115,22 @@ template <class T> class Solver final : public SolverBase {
             if (ctx->nranks > 1) throw Error(BZ_ERR_UNSUPPORTED, "slack (ALS) form is not sharded");
             n = nx + ny;
         }
-        if (d.c_kind != BZ_C_IDENTITY && d.c_kind != BZ_C_DENSE_AFFINE)
+        {
+            // generic (user-defined) oracles: host callbacks, all four together
+            const int ncb = (d.f_kind == BZ_F_CALLBACK) + (d.g_kind == BZ_G_CALLBACK) + (d.c_kind == BZ_C_CALLBACK) +
+                            (d.D_kind == BZ_D_CALLBACK);
+            if (ncb != 0 && ncb != 4)
+                throw Error(BZ_ERR_ARG, "generic oracles: f, g, c and D must all be the CALLBACK kind together");
+            generic_ = ncb == 4;
+            if (generic_) {
+                if (!d.cb_f_gradient || !d.cb_g_prox || !d.cb_c_eval || !d.cb_c_jtprod || !d.cb_D_proj)
+                    throw Error(BZ_ERR_ARG, "generic oracles: a callback pointer is null");
+                if (slack || ctx->nranks > 1)
+                    throw Error(BZ_ERR_UNSUPPORTED, "generic oracles: single rank, no slack form");
+                if (ny <= 0) throw Error(BZ_ERR_ARG, "generic oracles: ny must be positive");
+            }
+        }
+        if (d.c_kind != BZ_C_IDENTITY && d.c_kind != BZ_C_DENSE_AFFINE && !generic_)
             throw Error(BZ_ERR_UNSUPPORTED, "constraint kind not lowered to the device");
         if (d.c_kind == BZ_C_DENSE_AFFINE) {
             if (ny <= 0 || !d.c_A || !d.c_b) throw Error(BZ_ERR_ARG, "DenseAffine needs A[ny][n] and b[ny]");
@@ -125,7 +140,7 @@ template <class T> class Solver final : public SolverBase {
             if (ctx->nranks > 1 && (!ctx->p2p_on || slack))
                 throw Error(BZ_ERR_UNSUPPORTED, "a row-sharded DenseAffine needs the p2p mailboxes and no slack");
         }
-        if (d.f_kind < BZ_F_ZERO || d.f_kind > BZ_F_QUADRATIC)
+        if ((d.f_kind < BZ_F_ZERO || d.f_kind > BZ_F_QUADRATIC) && !generic_)
             throw Error(BZ_ERR_UNSUPPORTED, "smooth-cost kind not lowered to the device");
         dense_f = d.f_kind == BZ_F_LEAST_SQUARES || d.f_kind == BZ_F_QUADRATIC;
         if (dense_f) {
@@ -144,10 +159,10 @@ template <class T> class Solver final : public SolverBase {
             if (ctx->nranks > 1 && !ctx->p2p_on)
                 throw Error(BZ_ERR_UNSUPPORTED, "a sharded Stencil5pt needs the p2p mailboxes (bz_ctx_p2p_connect)");
         }
-        if (d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_NORM_LP_BOX)
+        if ((d.g_kind < BZ_G_ZERO || d.g_kind > BZ_G_NORM_LP_BOX) && !generic_)
             throw Error(BZ_ERR_ARG, "unknown g kind");
-        if (d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_XOR_PAIRS) throw Error(BZ_ERR_ARG, "unknown D kind");
-        if (d.D_kind >= BZ_D_VC_PAIRS) {
+        if ((d.D_kind < BZ_D_ZERO || d.D_kind > BZ_D_XOR_PAIRS) && !generic_) throw Error(BZ_ERR_ARG, "unknown D kind");
+        if (d.D_kind >= BZ_D_VC_PAIRS && d.D_kind <= BZ_D_XOR_PAIRS) {
             // adjacent pairs live inside one 16-byte pack: only the element-wise kernels (c = Identity) see them
             if (d.c_kind != BZ_C_IDENTITY || slack || d.f_kind == BZ_F_STENCIL5)
                 throw Error(BZ_ERR_UNSUPPORTED, "pairwise D sets need c = Identity, an element-wise or dense f and no slack");
@@ -249,6 +264,11 @@ template <class T> class Solver final : public SolverBase {
             if (d.D_hi_vec) { upload(dhi_, d.D_hi_vec, ny); P.D_hi_vec = dhi_.p; }
         }
         mu_.alloc(ny); muy_.alloc(ny); ymul_.alloc(ny); sproj_.alloc(ny);
+        if (generic_) {
+            const size_t nn = (size_t)std::max<int64_t>(n, ny);
+            for (auto* v : {&hx_, &hg_, &hy_, &hz_, &hres_, &hdfx_, &hjtv_}) v->assign(nn, T(0));
+            for (auto* v : {&hcx_, &ht_, &hs_, &hmu_, &hmuy_, &hyv_}) v->assign((size_t)ny, T(0));
+        }
         P.mu = mu_.p; P.muy = muy_.p;
         for (auto& b : X_) b.alloc(vcap);
         for (auto& b : RES_) b.alloc(vcap);
@@ -435,9 +455,29 @@ template <class T> class Solver final : public SolverBase {
         const double denom = std::max(1.0, (double)objx);
         const bool dense_c = desc.c_kind == BZ_C_DENSE_AFFINE;
         if (dense_c) eval_c(x);
+        if (generic_) {
+            // eval!(cx, c, x) ; proj!(s, D, cx) ; default_penalty_parameter!   (alps.jl:40-42, safeguards.jl:13-18:
+            // Float64 literals, stored back into T — the arithmetic of k_penalty_init)
+            copy_out(hx_.data(), x, n);
+            desc.cb_c_eval(desc.cb_user, hx_.data(), hcx_.data(), n, ny);
+            desc.cb_D_proj(desc.cb_user, hcx_.data(), hs_.data(), ny);
+            for (int64_t i = 0; i < ny; ++i) {
+                const T dd = hcx_[i] - hs_[i];
+                const double h = 0.5 * (double)(dd * dd);
+                T mm = (T)((h > 1.0 ? h : 1.0) / denom);
+                mm = (T)((double)mm * 0.1);
+                double w = (double)mm;
+                w = w < 1e8 ? w : 1e8;
+                w = w > 1e-8 ? w : 1e-8;
+                hmu_[i] = (T)w;
+            }
+            copy_in(sproj_.p, hs_.data(), ny);
+            copy_in(mu_.p, hmu_.data(), ny);
+        } else {
         mv(3 + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0), ny);
         launch(C_MISC, k_penalty_init<T>, grid_y, dense_c ? (const T*)CX_.p : (const T*)x /* cx = x */, P, denom,
                sproj_.p, mu_.p, ny);
+        }
         copy_in(ymul_.p, y0, ny);                                    // y .= y0
         double norm_res_prim = 0, norm_res_prim_old = 0;
         bool have_old = false, have_res = false;
@@ -465,9 +505,27 @@ template <class T> class Solver final : public SolverBase {
             const bool sub_solved = sub_it < ao.subsolver_maxit;     // alps.jl:70
             // dual update + primal residual                          alps.jl:72-84
             if (dense_c) eval_c(x);                                  // eval!(cx, c, x)  alps.jl:72
+            if (generic_) {
+                copy_out(hx_.data(), x, n);
+                desc.cb_c_eval(desc.cb_user, hx_.data(), hcx_.data(), n, ny);          // eval!(cx, c, x)      alps.jl:72
+                for (int64_t i = 0; i < ny; ++i) hyv_[i] = hcx_[i] + hmuy_[i];         // y .= cx .+ muy       :74
+                desc.cb_D_proj(desc.cb_user, hyv_.data(), hs_.data(), ny);             // proj!(s, D, y)       :75
+                double nrm = 0.0;
+                for (int64_t i = 0; i < ny; ++i) {
+                    T t = hyv_[i] - hs_[i];                                            // y .-= s              :80
+                    hyv_[i] = t / hmu_[i];                                             // y ./= mu             :81
+                    const T r = hcx_[i] - hs_[i];
+                    const double ar = (double)(r < T(0) ? -r : r);
+                    if (ar > nrm || ar != ar) nrm = ar;                                // norm(cx - s, Inf)    :84
+                }
+                copy_in(ymul_.p, hyv_.data(), ny);
+                copy_in(sproj_.p, hs_.data(), ny);
+                fill_slot(SL_OUTER, nrm);
+            } else {
             mv(3 + pstreams(false, true, false), ny);
             launch(C_MISC, k_dual_update<T>, grid_y, dense_c ? (const T*)CX_.p : (const T*)x, P, ymul_.p, sproj_.p,
                    ny, parts_.p, (int)SL_OUTER);
+            }
             gather(SL_OUTER, 1, 1u, 1u);
             auto r = collect({SL_OUTER}, 1u);
             norm_res_prim_old = norm_res_prim; have_old = have_res;
@@ -596,6 +654,59 @@ template <class T> class Solver final : public SolverBase {
     int rows_per_chunk = 1, nrowchunks = 1;
     DBuf<T> FA_, fb_, FR_, DFX_;             // dense f: matrix, vector, residual / Qx, gradient of f
     bool dense_f = false, lp_g = false;
+    // generic oracles (host callbacks): host mirrors of the vectors the callbacks read and write
+    bool generic_ = false;
+    std::vector<T> hx_, hg_, hy_, hz_, hres_, hdfx_, hjtv_, hcx_, ht_, hs_, hmu_, hmuy_, hyv_;
+    void fill_slot(int slot, double v) {
+        launch_b(C_MISC, k_fill_slot, 1, 64, parts_.p, slot, v);
+        slot_n[slot] = 1;
+    }
+    // gradient!(dlx, al, x) with the oracles evaluated on the host, statement by statement as
+    // src/utilities/auglagfun.jl:73-86 (the value-only form :58-69 is the same minus dfx and jtv)
+    void algrad_generic(const T* x, T* grad, int slot0) {
+        copy_out(hx_.data(), x, n);
+        desc.cb_c_eval(desc.cb_user, hx_.data(), hcx_.data(), n, ny);                  // eval!(cx, c, x)          :74
+        for (int64_t i = 0; i < ny; ++i) ht_[i] = hcx_[i] + hmuy_[i];                  // yupd .= cx .+ muy        :75
+        desc.cb_D_proj(desc.cb_user, ht_.data(), hs_.data(), ny);                      // proj!(s, D, yupd)        :76
+        double pen = 0.0;
+        for (int64_t i = 0; i < ny; ++i) {
+            T t = ht_[i] - hs_[i];                                                     // yupd .-= s               :77
+            pen += (double)((t * t) / hmu_[i]);                                        // sum(yupd.^2 ./ mu)       :78
+            ht_[i] = t / hmu_[i];                                                      // yupd ./= mu              :79
+        }
+        const double fx = desc.cb_f_gradient(desc.cb_user, hx_.data(), hdfx_.data(), n);   // fx = gradient!(dfx, f, x)  :80
+        if (grad) {
+            desc.cb_c_jtprod(desc.cb_user, hx_.data(), ht_.data(), hjtv_.data(), n, ny);   // jtprod!(jtv, c, x, yupd)   :83
+            for (int64_t j = 0; j < n; ++j) hg_[j] = hdfx_[j] + hjtv_[j];              // dlx .= dfx .+ jtv        :84
+            copy_in(grad, hg_.data(), n);
+        }
+        fill_slot(slot0, fx);
+        fill_slot(slot0 + 1, pen);
+    }
+    // y = x - gamma g ; z = prox!(., g, y, gamma) ; res = x - z   (nonsmoothcostfun.jl:17-22 and the caller's
+    // forward step), with the sums k_fbstep returns
+    void fbstep_generic(const T* x, const T* g, T gam, T* z, T* res, int slot0) {
+        copy_out(hx_.data(), x, n);
+        if (g) copy_out(hg_.data(), g, n);
+        for (int64_t j = 0; j < n; ++j) {
+            T yv = hx_[j];
+            if (g) { T t = gam * hg_[j]; yv = hx_[j] - t; }
+            hy_[j] = yv;
+        }
+        const double gz = desc.cb_g_prox(desc.cb_user, hy_.data(), (double)gam, hz_.data(), n);
+        double dot = 0.0, ss = 0.0;
+        for (int64_t j = 0; j < n; ++j) {
+            const T r = hx_[j] - hz_[j];
+            hres_[j] = r;
+            if (g) dot += (double)(hg_[j] * r);
+            ss += (double)(r * r);
+        }
+        copy_in(z, hz_.data(), n);
+        if (res) copy_in(res, hres_.data(), n);
+        fill_slot(slot0, gz);
+        fill_slot(slot0 + 1, dot);
+        fill_slot(slot0 + 2, ss);
+    }
     int64_t frows = 0, npad = 0;
     int f_rows_per_chunk = 1, f_nrowchunks = 1;
     T fscale = T(1);                         // f(x) = fscale * (sum of the f partials)
@@ -1073,6 +1184,7 @@ template <class T> class Solver final : public SolverBase {
     // forward-backward step kernel; the Newton/pow prox kinds use their own instantiation so the
     // common kinds keep their register budget
     void fbstep(const T* x, const T* g, T gam, T* z, T* res, int slot0) {
+        if (generic_) { fbstep_generic(x, g, gam, z, res, slot0); return; }
         if (slack) {
             for (int k = 0; k < 3; ++k) slot_n[slot0 + k] = grid_y;
             mv(2 * (1 + (g ? 1 : 0) + 1 + (res ? 1 : 0)) + pstreams(false, false, true) + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0), nx);
@@ -1097,6 +1209,7 @@ template <class T> class Solver final : public SolverBase {
         case BZ_G_NORM_L1: case BZ_G_NORM_L1_NONNEG: case BZ_G_NORM_L1_BOX: case BZ_G_NORM_L0_BOX:
         case BZ_G_NORM_LP_NONNEG: case BZ_G_NORM_LP_BOX:
             return P.g_lambda * T(gsum);
+        case BZ_G_CALLBACK: return T(gsum);      // the callback returned g(z) itself
         default: return T(0);
         }
     }
@@ -1157,6 +1270,7 @@ template <class T> class Solver final : public SolverBase {
         }
     }
     void algrad(const T* x, T* grad, int slot0) {
+        if (generic_) { algrad_generic(x, grad, slot0); return; }
         if (desc.c_kind == BZ_C_DENSE_AFFINE) {
             eval_c(x);                                                        // cx = A x - b
             mv(2 + pstreams(false, true, false), ny);
@@ -1206,6 +1320,11 @@ template <class T> class Solver final : public SolverBase {
     }
     // f(x) alone (alps.jl:39): partial sums -> slot0
     void fvalue(const T* x, int slot0) {
+        if (generic_) {      // f(x) through the gradient callback (the reference's generic f(x) needs no more)
+            copy_out(hx_.data(), x, n);
+            fill_slot(slot0, desc.cb_f_gradient(desc.cb_user, hx_.data(), hdfx_.data(), n));
+            return;
+        }
         slot_n[slot0] = grid;
         if (slack) {      // f on the x part only
             slot_n[slot0] = grid_y;
@@ -1239,6 +1358,7 @@ template <class T> class Solver final : public SolverBase {
         const int uni_env = std::getenv("BZ_UNI") ? std::atoi(std::getenv("BZ_UNI")) : 2;      // (tests toggle it)
         const bool probe = uni_env && fused_family() >= 0;
         for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
+        slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
         mv(3 + (safeguard ? 1 : 0), ny);
         launch(C_MISC, k_muy<T>, grid_y, (const T*)mu_.p, ymul_.p, muy_.p, ny, parts_.p, (int)SL_OUTER,
                safeguard ? 1 : 0, probe ? (int)SL_GP : -1);
@@ -1260,6 +1380,7 @@ template <class T> class Solver final : public SolverBase {
         }
         if (v[1] > 0.0) throw Error(BZ_ERR_MU, "parameters `mu` must be positive");
         musqy = T(0.5) * T(v[0]);
+        if (generic_) { copy_out(hmu_.data(), mu_.p, ny); copy_out(hmuy_.data(), muy_.p, ny); }
         if (probe && u[1] == 0.0 && u[0] > 0.0) {
             uni_ = (u[2] == 0.0 && uni_env >= 2) ? 2 : 1;
             P.mu_uniform = (T)u[0];
@@ -1690,6 +1811,7 @@ template <class T> class Solver final : public SolverBase {
     void display() {
         ensure_z();
         mv(1);
+        slot_n[SL_AUX] = grid;
         launch(C_MISC, k_absmax<T>, grid, (const T*)RES_[rc].p, n, parts_.p, (int)SL_AUX);
         gather(SL_AUX, 1, 1u);
         auto v = collect({SL_AUX}, 1u);

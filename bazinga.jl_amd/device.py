@@ -116,10 +116,23 @@ class Problem:
         desc, keep = lower(f, g, c, D, self.nx, self.ny, self.dtype, slack)
         h = C.c_void_p()
         L.check(L.load().bz_problem_create(self.ctx._h, C.byref(desc), C.byref(h)))
+        # structured oracles: the library has copied the data.  Generic oracles: the callback thunks (and the list
+        # exceptions raised inside them are parked in) must live as long as the problem
+        self.generic = desc.f_kind == L.BZ_F_CALLBACK
+        self._keep = keep if self.generic else None
         del keep
         self._h = h
 
     # -- helpers
+    def _call(self, rc):
+        """check a library return code; an exception raised inside an oracle callback surfaces here"""
+        if self._keep is not None and self._keep[-1]:
+            err = self._keep[-1][0]
+            del self._keep[-1][:]
+            from .oracles import CallbackError
+            raise CallbackError(f"oracle callback raised {type(err).__name__}: {err}") from err
+        L.check(rc)
+
     def _in(self, a, n):
         v = np.ascontiguousarray(a, dtype=self.dtype)
         if v.shape != (n,):
@@ -128,18 +141,18 @@ class Problem:
 
     def set_multipliers(self, mu, y):
         mu, y = self._in(mu, self.ny), self._in(y, self.ny)
-        L.check(L.load().bz_problem_set_multipliers(self._h, mu.ctypes.data, y.ctypes.data))
+        self._call(L.load().bz_problem_set_multipliers(self._h, mu.ctypes.data, y.ctypes.data))
 
     def panoc_solve(self, opts: L.PanocOpts, x0):
         x0 = self._in(x0, self.n)
         out = np.empty(self.n, self.dtype)
         st = L.PanocStats()
-        L.check(L.load().bz_panoc_solve(self._h, C.byref(opts), x0.ctypes.data, out.ctypes.data, C.byref(st)))
+        self._call(L.load().bz_panoc_solve(self._h, C.byref(opts), x0.ctypes.data, out.ctypes.data, C.byref(st)))
         return out, st
 
     def panoc_begin(self, opts: L.PanocOpts, x0):
         x0 = self._in(x0, self.n)
-        L.check(L.load().bz_panoc_begin(self._h, C.byref(opts), x0.ctypes.data))
+        self._call(L.load().bz_panoc_begin(self._h, C.byref(opts), x0.ctypes.data))
 
     def halo_export(self) -> bytes:
         """Row-block-sharded Stencil5ptQuadratic: this rank's halo region (64-byte IPC handle)."""
@@ -165,16 +178,16 @@ class Problem:
         L.check(L.load().bz_problem_allreduce_connect(self._h, blob))
 
     def panoc_step(self):
-        L.check(L.load().bz_panoc_step(self._h))
+        self._call(L.load().bz_panoc_step(self._h))
 
     def panoc_steps(self, k: int):
         """k consecutive Base.iterate(iter, state) steps in one library call."""
-        L.check(L.load().bz_panoc_steps(self._h, int(k)))
+        self._call(L.load().bz_panoc_steps(self._h, int(k)))
 
     def panoc_finish(self):
         out = np.empty(self.n, self.dtype)
         st = L.PanocStats()
-        L.check(L.load().bz_panoc_finish(self._h, out.ctypes.data, C.byref(st)))
+        self._call(L.load().bz_panoc_finish(self._h, out.ctypes.data, C.byref(st)))
         return out, st
 
     def panoc_stats(self):
@@ -193,7 +206,7 @@ class Problem:
     def panoc_vector(self, which):
         idx = {"x": 0, "z": 1, "res": 2, "grad_x": 3, "grad_z": 4}[which]
         out = np.empty(self.n, self.dtype)
-        L.check(L.load().bz_panoc_vector(self._h, idx, out.ctypes.data))
+        self._call(L.load().bz_panoc_vector(self._h, idx, out.ctypes.data))
         return out
 
     def alps_solve(self, aopts: L.AlpsOpts, popts: L.PanocOpts, x0, y0):
@@ -202,7 +215,7 @@ class Problem:
         y, s, mu = (np.empty(self.ny, self.dtype) for _ in range(3))
         st = L.AlpsStats()
         fn = L.load().bz_als_solve if self.slack else L.load().bz_alps_solve
-        L.check(fn(self._h, C.byref(aopts), C.byref(popts), x0.ctypes.data, y0.ctypes.data,
+        self._call(fn(self._h, C.byref(aopts), C.byref(popts), x0.ctypes.data, y0.ctypes.data,
                                        x.ctypes.data, y.ctypes.data, s.ctypes.data, mu.ctypes.data, C.byref(st)))
         return x, y, s, mu, st
 
@@ -210,14 +223,14 @@ class Problem:
         x = self._in(x, self.n)
         g = np.empty(self.n, self.dtype)
         vals = (C.c_double * 3)()
-        L.check(L.load().bz_eval_al_gradient(self._h, x.ctypes.data, g.ctypes.data, vals))
+        self._call(L.load().bz_eval_al_gradient(self._h, x.ctypes.data, g.ctypes.data, vals))
         return g, tuple(vals)
 
     def eval_prox(self, x, gamma):
         x = self._in(x, self.n)
         z = np.empty(self.n, self.dtype)
         gz = C.c_double()
-        L.check(L.load().bz_eval_prox(self._h, x.ctypes.data, float(gamma), z.ctypes.data, C.byref(gz)))
+        self._call(L.load().bz_eval_prox(self._h, x.ctypes.data, float(gamma), z.ctypes.data, C.byref(gz)))
         return z, gz.value
 
     def eval_lbfgs(self, S, Y, v):

@@ -3,12 +3,26 @@
 The reference's oracles are duck-typed Julia structs (README.md:17-20,
 src/Bazinga.jl:7-16).  A device cannot run arbitrary closures, so the host side
 pattern-matches the structured types below and lowers them to a C descriptor
-(`bz_problem_desc`, include/bazinga_hip.h).  Anything else raises
-``UnsupportedOracle`` — there is no CPU fallback in the product path.
+(`bz_problem_desc`, include/bazinga_hip.h).
+
+Anything else is a GENERIC oracle (demo/rosenbrock.jl:39-80 — BASELINE config 1): an object with
+the reference's protocol
+
+    f.gradient(dfx, x) -> f(x)        gradient!(dfx, f, x)       src/Bazinga.jl:16
+    g.prox(z, x, gamma) -> g(z)       prox!(z, g, x, gamma)      src/Bazinga.jl:15
+    c.eval(cx, x), c.jtprod(jtv, x, v)                           src/Bazinga.jl:11-12
+    D.proj(s, v)                      proj!(s, D, v)             src/Bazinga.jl:14
+
+is handed to the library as host callbacks (BZ_*_CALLBACK): the host evaluates the oracles, the
+device keeps the L-BFGS / line-search vector work.  When one of the four is generic all four travel
+as callbacks (the structured types below carry the same protocol for that case).  An object with
+neither raises ``UnsupportedOracle``; nothing ever falls back to a CPU solver.
 """
 from __future__ import annotations
 
 import numpy as np
+
+import ctypes as C
 
 from . import _lib as L
 
@@ -34,6 +48,14 @@ class ClosedSetBase:        # src/Bazinga.jl:9  (abstract type ClosedSet)
 class Zero(ProximableFunction):
     """src/proxoperators/zero.jl:11-25; usable as f or g."""
 
+    def gradient(self, dfx, x):
+        dfx[...] = 0
+        return x.dtype.type(0)
+
+    def prox(self, z, x, gamma):
+        z[...] = x
+        return x.dtype.type(0)
+
 
 class DiagQuadratic(ProximableFunction):
     """f(x) = sum_i x_i (0.5 q_i x_i - b_i) — diagonal special case of
@@ -45,6 +67,11 @@ class DiagQuadratic(ProximableFunction):
         if self.q.shape != self.b.shape or self.q.ndim != 1:
             raise ValueError("q and b must be vectors of equal length")
 
+    def gradient(self, dfx, x):
+        qx = self.q * x
+        dfx[...] = qx - self.b
+        return np.sum(x * (x.dtype.type(0.5) * qx - self.b))
+
 
 class LeastSquares(ProximableFunction):
     """ProximalOperators.LeastSquares(A, b): f(x) = 0.5||A x - b||^2 (test/problems/test_verbose.jl:22)."""
@@ -54,6 +81,11 @@ class LeastSquares(ProximableFunction):
         self.b = np.ascontiguousarray(b)
         if self.A.ndim != 2 or self.b.shape != (self.A.shape[0],):
             raise ValueError("A must be m-by-n and b of length m")
+
+    def gradient(self, dfx, x):
+        r = self.A @ x - self.b
+        dfx[...] = self.A.T @ r
+        return x.dtype.type(0.5) * np.dot(r, r)
 
 
 class Quadratic(ProximableFunction):
@@ -65,6 +97,11 @@ class Quadratic(ProximableFunction):
         self.q = np.ascontiguousarray(q)
         if self.Q.ndim != 2 or self.Q.shape[0] != self.Q.shape[1] or self.q.shape != (self.Q.shape[0],):
             raise ValueError("Q must be n-by-n and q of length n")
+
+    def gradient(self, dfx, x):
+        Qx = self.Q @ x
+        dfx[...] = Qx + self.q
+        return x.dtype.type(0.5) * np.dot(x, Qx) + np.dot(self.q, x)
 
 
 class Stencil5ptQuadratic(ProximableFunction):
@@ -83,6 +120,10 @@ class Stencil5ptQuadratic(ProximableFunction):
 class IndFree(ProximableFunction):
     """ProximalOperators.IndFree (test_nonconvex_qp.jl:39)."""
 
+    def prox(self, z, x, gamma=1.0):
+        z[...] = x
+        return x.dtype.type(0)
+
 
 class NormL1(ProximableFunction):
     """ProximalOperators.NormL1(lambda) (test_verbose.jl:23, demo/basispursuit.jl:63)."""
@@ -92,6 +133,11 @@ class NormL1(ProximableFunction):
             raise ValueError("parameter λ must be nonnegative")
         self.lam = float(lam)
 
+    def prox(self, z, x, gamma):
+        gl = x.dtype.type(gamma * self.lam)
+        z[...] = x + np.where(x <= -gl, gl, np.where(x >= gl, -gl, -x))
+        return x.dtype.type(self.lam) * np.sum(np.abs(z))
+
 
 class NormL1Nonneg(ProximableFunction):
     """src/proxoperators/normL1Nonneg.jl:9-42"""
@@ -100,6 +146,11 @@ class NormL1Nonneg(ProximableFunction):
         if lam < 0:
             raise ValueError("λ must be nonnegative")
         self.lam = float(lam)
+
+    def prox(self, z, x, gamma):
+        gl = x.dtype.type(gamma * self.lam)
+        z[...] = np.where(x >= gl, x - gl, 0)
+        return x.dtype.type(self.lam) * np.sum(z)
 
 
 class NormL1Box(ProximableFunction):
@@ -112,6 +163,11 @@ class NormL1Box(ProximableFunction):
         if np.any(self.u < 0):
             raise ValueError("vector u must have nonnegative entries")
         self.lam = float(lam)
+
+    def prox(self, z, x, gamma):
+        gl = x.dtype.type(gamma * self.lam)
+        z[...] = np.maximum(0, np.minimum(x - gl, self.u))
+        return x.dtype.type(self.lam) * np.sum(z)
 
 
 class NormL0Box(ProximableFunction):
@@ -164,10 +220,20 @@ class IndBox(ProximableFunction):
         if np.any(np.asarray(lb) > np.asarray(ub)):
             raise ValueError("bounds must satisfy lb <= ub")
 
+    def prox(self, z, x, gamma=1.0):
+        z[...] = np.where(x < self.lb, self.lb, np.where(x > self.ub, self.ub, x))
+        return x.dtype.type(0)
+
 
 # ------------------------------------------------------------------------- c
 class IdentityFunction(SmoothFunction):
     """test/definitions/identityFunction.jl:3-13"""
+
+    def eval(self, cx, x):
+        cx[...] = x
+
+    def jtprod(self, jtv, x, v):
+        jtv[...] = v
 
 
 class DenseAffine(SmoothFunction):
@@ -180,14 +246,26 @@ class DenseAffine(SmoothFunction):
         if self.A.ndim != 2 or self.b.shape != (self.A.shape[0],):
             raise ValueError("A must be ny-by-n and b of length ny")
 
+    def eval(self, cx, x):
+        cx[...] = self.A @ x - self.b
+
+    def jtprod(self, jtv, x, v):
+        jtv[...] = self.A.T @ v
+
 
 # ------------------------------------------------------------------------- D
 class ZeroSet(ClosedSetBase):
     """src/projections/zeroSet.jl:8-20"""
 
+    def proj(self, s, v):
+        s[...] = 0
+
 
 class FreeSet(ClosedSetBase):
     """src/projections/freeSet.jl:8-20"""
+
+    def proj(self, s, v):
+        s[...] = v
 
 
 class IndicatorSet(ClosedSetBase):
@@ -195,6 +273,9 @@ class IndicatorSet(ClosedSetBase):
 
     def __init__(self, f):
         self.f = f
+
+    def proj(self, s, v):
+        self.f.prox(s, v, 1.0)
 
 
 def ClosedSet(f):
@@ -214,6 +295,34 @@ class PairwiseSet(ClosedSetBase):
         if kind not in self.KINDS:
             raise ValueError(f"kind must be one of {self.KINDS}")
         self.kind = kind
+
+    def proj(self, s, v):
+        """the 2-element projections over adjacent pairs (host protocol: only used when another oracle of the
+        problem is generic)"""
+        x1, x2 = v[0::2], v[1::2]
+        z1, z2 = x1.copy(), x2.copy()
+        if self.kind == "vc":          # vanishingConstraints.jl:27-46
+            a = x1 <= 0
+            b = ~a & (x2 >= 0)
+            c = ~a & ~b & (x1 + x2 > 0)
+            z1[...] = np.where(b | c, x1, 0)
+            z2[...] = np.where(a | b | ~c, x2, 0)
+            z2[c] = 0
+        elif self.kind == "cc":        # complementarityConstraints.jl:8-20
+            both = (x1 > 0) & (x2 > 0)
+            z1[...] = np.where(both, np.where(x2 > x1, 0, x1), np.maximum(x1, 0))
+            z2[...] = np.where(both, np.where(x2 > x1, x2, 0), np.maximum(x2, 0))
+        elif self.kind == "eitheror":  # orConstraints.jl:7-17
+            both = (x1 < 0) & (x2 < 0)
+            z1[...] = np.where(both & (x1 > x2), 0, x1)
+            z2[...] = np.where(both & ~(x1 > x2), 0, x2)
+        else:                          # xor, orConstraints.jl:24-36
+            same = x1 * x2 > 0
+            up = x1 > x2
+            z1[...] = np.where(same, np.where(up, np.maximum(x1, 0), np.minimum(x1, 0)), x1)
+            z2[...] = np.where(same, np.where(up, np.minimum(x2, 0), np.maximum(x2, 0)), x2)
+        s[0::2] = z1
+        s[1::2] = z2
 
 
 def VanishingConstraintPairs():
@@ -240,10 +349,77 @@ def _vec(a, dtype, n, name):
     return v
 
 
+_LOWERED_F = lambda f: isinstance(f, (Zero, DiagQuadratic, LeastSquares, Quadratic, Stencil5ptQuadratic))
+_LOWERED_G = lambda g: isinstance(g, (Zero, IndFree, NormL1, NormL1Nonneg, NormL1Box, NormL0Box, NormLpPowerNonneg,
+                                      NormLpPowerBox, IndBox))
+_LOWERED_C = lambda c: isinstance(c, (IdentityFunction, DenseAffine))
+_LOWERED_D = lambda D: isinstance(D, (ZeroSet, FreeSet, PairwiseSet)) or \
+    (isinstance(D, IndicatorSet) and isinstance(D.f, (IndBox, IndFree)))
+
+
+class CallbackError(RuntimeError):
+    """An oracle callback raised: the original exception is the __cause__."""
+
+
+def lower_generic(f, g, c, D, n, ny, dtype, slack=False):
+    """Generic oracles -> host callbacks (BZ_*_CALLBACK).  Returns (desc, keep): `keep` holds the ctypes thunks and
+    must live as long as the problem; keep[-1] is the list exceptions raised inside callbacks are parked in."""
+    if slack:
+        raise UnsupportedOracle("generic (callback) oracles are not available in the slack (ALS) form")
+    for obj, names, what in ((f, ("gradient",), "f"), (g, ("prox",), "g"), (c, ("eval", "jtprod"), "c"), (D, ("proj",), "D")):
+        for nm in names:
+            if not callable(getattr(obj, nm, None)):
+                raise UnsupportedOracle(f"{what} of type {type(obj).__name__} is neither a lowered oracle type nor a generic "
+                                        f"one (no `{nm}` method)")
+    dt = np.dtype(dtype)
+    errors = []
+
+    ctype = C.c_double if dt == np.float64 else C.c_float
+
+    def arr(ptr, cnt):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(cnt,))
+
+    def guard(fn, default):
+        def wrapped(*a):
+            try:
+                return fn(*a)
+            except BaseException as e:      # noqa: BLE001  (nothing may unwind through the C frames)
+                errors.append(e)
+                return default
+        return wrapped
+
+    def f_gradient(_u, px, pdfx, nn):
+        return float(f.gradient(arr(pdfx, nn), arr(px, nn)))
+
+    def g_prox(_u, px, gamma, pz, nn):
+        return float(g.prox(arr(pz, nn), arr(px, nn), dt.type(gamma)))
+
+    def c_eval(_u, px, pcx, nn, nny):
+        c.eval(arr(pcx, nny), arr(px, nn))
+
+    def c_jtprod(_u, px, pv, pjtv, nn, nny):
+        c.jtprod(arr(pjtv, nn), arr(px, nn), arr(pv, nny))
+
+    def d_proj(_u, pv, ps, nny):
+        D.proj(arr(ps, nny), arr(pv, nny))
+
+    d = L.ProblemDesc()
+    d.dtype = L.BZ_F64 if dt == np.float64 else L.BZ_F32
+    d.n, d.ny, d.slack = n, ny, 0
+    d.f_kind, d.g_kind, d.c_kind, d.D_kind = L.BZ_F_CALLBACK, L.BZ_G_CALLBACK, L.BZ_C_CALLBACK, L.BZ_D_CALLBACK
+    nan = float("nan")
+    thunks = [L.F_GRADIENT_FN(guard(f_gradient, nan)), L.G_PROX_FN(guard(g_prox, nan)), L.C_EVAL_FN(guard(c_eval, None)),
+              L.C_JTPROD_FN(guard(c_jtprod, None)), L.D_PROJ_FN(guard(d_proj, None))]
+    d.cb_f_gradient, d.cb_g_prox, d.cb_c_eval, d.cb_c_jtprod, d.cb_D_proj = thunks
+    return d, [f, g, c, D, thunks, errors]
+
+
 def lower(f, g, c, D, n, ny, dtype, slack=False):
     """(f, g, c, D) -> (ProblemDesc, keepalive list).  Raises UnsupportedOracle.
     slack=True: the ALS form on xs = [x; s] (src/utilities/auglagfunslack.jl)."""
     dtype = np.dtype(dtype)
+    if dtype in (np.float64, np.float32) and not (_LOWERED_F(f) and _LOWERED_G(g) and _LOWERED_C(c) and _LOWERED_D(D)):
+        return lower_generic(f, g, c, D, n, ny, dtype, slack)
     if dtype == np.float64:
         code = L.BZ_F64
     elif dtype == np.float32:

@@ -255,7 +255,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     probe.set_multipliers(np.ones_like(y0), np.zeros_like(y0))
     _, vals = probe.eval_al_gradient(x)
     objx = T(vals[1]) + gFun.gz                                 # :39
-    cx[...] = _eval_c_host(c, x)                                # :40
+    cx[...] = _eval_c_host(c, x, cx.shape[0])                                # :40
     s[...] = _proj_host(D, cx)                                  # :41
     default_penalty_parameter(mu, cx, s, objx)                  # :42
     y[...] = y0                                                 # :43
@@ -286,7 +286,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         objx = alFun.fx + gFun.gz                               # :68
         tot_inner_it += sub_it
         sub_solved = sub_it < subsolver_maxit                   # :70
-        cx[...] = _eval_c_host(c, x)                            # :72
+        cx[...] = _eval_c_host(c, x, cx.shape[0])                            # :72
         np.add(cx, alFun.muy, out=y)                            # :74
         s[...] = _proj_host(D, y)                               # :75
         y -= s                                                  # :80
@@ -340,7 +340,7 @@ def _als_host_loop(f, g, c, D, x, y, cx, s, mu, gFun, objx, tol_prim, tol_dual, 
         objx = fSlack.fx + gSlack.gz                            # :79  f(x) at the returned point
         tot_inner_it += sub_it
         sub_solved = sub_it < subsolver_maxit
-        cx[...] = _eval_c_host(c, x)                            # :82
+        cx[...] = _eval_c_host(c, x, cx.shape[0])                            # :82
         y[...] = y + (cx - s) / mu                              # :84
         norm_res_prim_old = norm_res_prim
         norm_res_prim = np.max(np.abs(cx - s))                  # :87
@@ -359,13 +359,17 @@ def _als_host_loop(f, g, c, D, x, y, cx, s, mu, gFun, objx, tol_prim, tol_dual, 
     return x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu
 
 
-def _eval_c_host(c, x):
+def _eval_c_host(c, x, ny=None):
     """eval!(cx, c, x) for the host outer loop's O(ny) bookkeeping (outside the hot path)."""
     from .oracles import DenseAffine, IdentityFunction
     if isinstance(c, IdentityFunction):
         return x
     if isinstance(c, DenseAffine):
         return (c.A @ x - c.b).astype(x.dtype, copy=False)
+    if callable(getattr(c, "eval", None)) and ny is not None:      # generic oracle: the reference's protocol
+        cx = np.empty(ny, x.dtype)
+        c.eval(cx, x)
+        return cx
     raise UnsupportedOracle(f"c of type {type(c).__name__} is not lowered")
 
 
@@ -379,4 +383,8 @@ def _proj_host(D, v):
         return v.copy()
     if isinstance(D, IndicatorSet) and isinstance(D.f, IndBox):
         return np.where(v < D.f.lb, D.f.lb, np.where(v > D.f.ub, D.f.ub, v)).astype(v.dtype, copy=False)
+    if callable(getattr(D, "proj", None)):                          # generic oracle / pairwise sets
+        s = np.empty_like(v)
+        D.proj(s, v)
+        return s
     raise UnsupportedOracle(f"D of type {type(D).__name__} is not lowered")

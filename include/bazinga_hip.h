@@ -77,6 +77,28 @@ extern "C" {
 #define BZ_D_EITHEROR_PAIRS  5   /* project_onto_EITHEROR_set! src/projections/orConstraints.jl:7-17           */
 #define BZ_D_XOR_PAIRS       6   /* project_onto_XOR_set!      src/projections/orConstraints.jl:24-36          */
 
+/* Generic (user-defined) oracles — whatever the structured kinds above do not cover, e.g. the closures of
+ * demo/rosenbrock.jl:39-80 (BASELINE config 1): the four oracles are HOST CALLBACKS with the reference's own
+ * protocol (README.md:17-20; the generic fallbacks the package itself defines are src/Bazinga.jl:49-84).  The host
+ * evaluates f/grad f, prox_g, c, J'v and proj_D and assembles the AL gradient exactly as auglagfun.jl:73-86 does;
+ * the L-BFGS two-loop, the line-search vector work and every reduction stay on the device.  All four kinds must be
+ * the CALLBACK kind together (a host language wraps its structured types in callbacks when it mixes them);
+ * single rank, no slack form.  Every vector a callback sees is a host array of the problem's dtype.        */
+#define BZ_F_CALLBACK        5
+#define BZ_G_CALLBACK        8
+#define BZ_C_CALLBACK        2
+#define BZ_D_CALLBACK        7
+/* gradient!(dfx, f, x) -> f(x)                       src/Bazinga.jl:16, demo/rosenbrock.jl:45-50          */
+typedef double (*bz_f_gradient_fn)(void* user, const void* x, void* dfx, int64_t n);
+/* prox!(z, g, x, gamma) -> g(z)                      src/utilities/nonsmoothcostfun.jl:17-22              */
+typedef double (*bz_g_prox_fn)(void* user, const void* x, double gamma, void* z, int64_t n);
+/* eval!(cx, c, x)                                    demo/rosenbrock.jl:67-70                             */
+typedef void (*bz_c_eval_fn)(void* user, const void* x, void* cx, int64_t n, int64_t ny);
+/* jtprod!(jtv, c, x, v)                              demo/rosenbrock.jl:71-74                             */
+typedef void (*bz_c_jtprod_fn)(void* user, const void* x, const void* v, void* jtv, int64_t n, int64_t ny);
+/* proj!(s, D, v)                                     demo/rosenbrock.jl:77-80                             */
+typedef void (*bz_D_proj_fn)(void* user, const void* v, void* s, int64_t ny);
+
 typedef struct bz_ctx     bz_ctx;
 typedef struct bz_problem bz_problem;
 
@@ -150,6 +172,13 @@ typedef struct {
     double      D_lo, D_hi;        /* BOX scalar bounds (+-inf allowed)               */
     const void* D_lo_vec;          /* BOX vector bounds (or NULL)                     */
     const void* D_hi_vec;
+    /* generic oracles (all four kinds BZ_*_CALLBACK) */
+    void*            cb_user;      /* handed back to every callback                   */
+    bz_f_gradient_fn cb_f_gradient;
+    bz_g_prox_fn     cb_g_prox;
+    bz_c_eval_fn     cb_c_eval;
+    bz_c_jtprod_fn   cb_c_jtprod;
+    bz_D_proj_fn     cb_D_proj;
 } bz_problem_desc;
 
 int  bz_problem_create(bz_ctx* ctx, const bz_problem_desc* desc, bz_problem** out);

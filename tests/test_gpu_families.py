@@ -119,14 +119,16 @@ def test_family_forms_are_bitwise_neutral(bz, ref, fam):
     iters = 70
     pin = {"BZ_GFC": "2", "BZ_GRID": "512", "BZ_TRIALFUSE": "0"}      # one summation tree for every form
     base = _run(bz, dev, n, mu, y, x0, iters, dict(pin, BZ_XR="0"))
-    assert base[5] == 0 and base[4][3] >= iters - 12              # stored-pair form, fused (almost) throughout
+    # stored-pair form, fused throughout but for the iterations with a tau backtrack or a gamma halving
+    assert base[5] == 0 and base[4][3] >= iters - 12 - base[4][0] - base[4][1]
     variants = [dict(pin, BZ_XR="2", BZ_UNI="0"), dict(pin, BZ_XR="2"), dict(pin, BZ_XR="2", BZ_TRIALFUSE="1"),
                 dict(pin, BZ_XR="2", BZ_SKIPZ="0")]
     if fam == ("diag", "l1", "box"):
         variants.append(dict(pin, BZ_XR="2", BZ_FAMRT="1", BZ_TRIALFUSE="1"))
     for env in variants:
         r = _run(bz, dev, n, mu, y, x0, iters, env)
-        assert r[5] >= iters - 12 - 2 * base[4][2], (env, r[5], base[4])      # the iterate-history form really ran
+        # the iterate-history form really ran (a skipped pair or a rejected trial sends a few iterations elsewhere)
+        assert r[5] >= max(10, iters - 12 - 6 * base[4][2] - 2 * base[4][0] - base[4][1]), (env, r[5], base[4])
         if fam != ("diag", "l1", "box") or env.get("BZ_FAMRT"):
             assert "FAM=" in r[6], r[6]                                     # ... in its family instantiation
         for a, b in zip(r[:3], base[:3]):
@@ -143,7 +145,7 @@ def test_family_forms_are_bitwise_neutral(bz, ref, fam):
     # the generic kernel chain (fuse = False) on the same grid: same values (p, w come from another kernel's sums)
     g = _run(bz, dev, n, mu, y, x0, 25, dict(pin), fuse=False, compact=True)
     f = _run(bz, dev, n, mu, y, x0, 25, dict(pin, BZ_XR="2"))
-    assert g[4][3] == 0 and f[4][3] >= 20
+    assert g[4][3] == 0 and f[4][3] >= 20 - f[4][0] - f[4][1]
     assert np.max(np.abs(g[0] - f[0])) <= 1e-11 * max(1.0, np.max(np.abs(f[0])))
     assert np.max(np.abs(g[1] - f[1])) <= 1e-11 * max(1.0, np.max(np.abs(f[1])))
 

@@ -720,6 +720,7 @@ template <class T> class Solver final : public SolverBase {
     int num_cus = 0, persist_kr = 0;
     int64_t vcap = 0;                        // allocated elements per n-vector (>= n, zero-padded)
     bool persist_ok = false;
+    bool stencil_fast_ = false;              // Stencil5pt f with the two fused stencil passes (see step())
     bool persist_broken_ = false;            // a grid barrier timed out once on this problem: the kernel chain from then on
     bool persist_sabotage_ = false;          // BZ_TEST_PERSIST_TIMEOUT=1: make the barrier miss its target (tests the fallback)
     std::vector<DBuf<T>> S_, Y_;
@@ -1682,7 +1683,10 @@ template <class T> class Solver final : public SolverBase {
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
         // auto: the compact representation where it makes the whole iteration one pass (the fused separable
         // path, memory within its capacity), the two-loop recursion everywhere else
-        compact_ok = M >= 1 && (o.lbfgs_compact == 1 || (o.lbfgs_compact == 2 && fused_ok && M <= CM));
+        // (... and the stencil path: x_d, k_stencil_fb, k_stencil_update_c with ONE reduction phase per iteration
+        // instead of the persistent two-loop kernel's 2m - 1 grid barriers, or 2m + 1 exchanges when sharded)
+        stencil_fast_ = desc.f_kind == BZ_F_STENCIL5 && o.fuse && !lp_g && !slack;
+        compact_ok = M >= 1 && (o.lbfgs_compact == 1 || (o.lbfgs_compact == 2 && (fused_ok || stencil_fast_) && M <= CM));
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
             // block per CU) and the vector must be long enough for 2m-1 grid barriers to beat 2m launches
@@ -1859,7 +1863,8 @@ template <class T> class Solver final : public SolverBase {
         // direction d = H(-res): all but the last axpy
         // (headline family: the one-pass kernel also serves an EMPTY memory — d = H0 (-res), all coefficients zero —
         // so the first iteration of a solve is a 3..5-stream pass too instead of k_fused_sep's 12)
-        const bool use_compact = compact_ok && (!order.empty() || (fused_ok && fused_family() >= 0));
+        const bool use_compact = compact_ok && (!order.empty() || (fused_ok && fused_family() >= 0) ||
+                                                (stencil_fast_ && !ctx->multi()));
         const bool use_persist = persist_ok && !order.empty() && !use_compact;
         CompactVecs<T, CM> CV;
         CompactCoef<CM> CC;
@@ -2045,7 +2050,7 @@ template <class T> class Solver final : public SolverBase {
                 launch(C_XD, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
                        parts_.p, 0);
             }
-            if (desc.f_kind == BZ_F_STENCIL5 && opt.fuse && !lp_g && !slack && !ctx->multi()) {
+            if (stencil_fast_ && !ctx->multi()) {
                 // stencil fast path: {AL gradient at x_d + FB step} and {AL gradient at z + pair + stop norm}
                 // as two passes; same partial sums as the four generic kernels of the first trial
                 for (int sidx = SL_FXD; sidx <= SL_STOP; ++sidx) slot_n[sidx] = grid;
@@ -2054,12 +2059,23 @@ template <class T> class Solver final : public SolverBase {
                 launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                        (int)SL_GSUM);
+                if (use_compact) {
+                    // ... with the Gram products of the new pair and the next application's p, w in the same pass
+                    for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
+                    mv(2 + pstreams(false, true, false) + 5 + 2 + 2 * CV.m);
+                    nm("k_stencil_update_c");
+                    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
+                           (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
+                           (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
+                    gram_from_trial = true;
+                } else {
                 mv(2 + pstreams(false, true, false) + 5 + 2);   // z, b + parameters, x_d, x, res, res_prev, grad ; s, y
                 nm("k_stencil_update");
                 launch(C_STENCIL_UPD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
                        (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, (T*)nullptr, n, parts_.p,
                        (int)SL_FZ, (int)SL_YS);
+                }
                 have_trial = true; gx_valid = true; gz_valid = false;
                 n_grad += 2; n_prox += 1;
             } else {

@@ -468,6 +468,11 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 (default, the headline metric); cfg3 2048^2 stencil QP; cfg4 dense-A basis "
                          "pursuit fp32; cfg5 = cfg2 at n=1e8")
+    ap.add_argument("--family", default="diag-l1-box",
+                    help="cfg2 / cfg5 with another element-wise oracle family f-g-D: f in diag|zero, g in "
+                         "zero|l1|nonneg|l1box|indbox|indboxvec, D in box|boxvec|boxveclo|free|zero|vc|cc|eitheror|xor "
+                         "(default: the BASELINE workload).  Same sizes, same JSON; every family has its own instantiation "
+                         "of the one-pass kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-states", type=int, default=31)
     ap.add_argument("--no-fuse", action="store_true")
@@ -546,9 +551,30 @@ def main():
     popts = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=float(np.finfo(float).eps),
                          fuse=not args.no_fuse, directions=bz.LBFGS(M_LBFGS, compact=compact)).c_opts()
 
+    fam = tuple(args.family.split("-"))
+    if len(fam) != 3:
+        raise SystemExit("--family must be f-g-D")
+    headline = fam == ("diag", "l1", "box")
+
+    def family_oracles():
+        """(f, g, c, D) of --family on this rank's shard: the BASELINE data (q, b, lambda, [-1, 1]) wherever the family
+        has the corresponding parameter, deterministic splitmix64 streams for the vector bounds"""
+        fk, gk, dk = fam
+        u6 = lambda k: bz.synth.uniform(k, nl, lo_i)
+        f = bz.DiagQuadratic(d["q"], d["b"]) if fk == "diag" else bz.Zero()
+        g = {"zero": lambda: bz.Zero(), "l1": lambda: bz.NormL1(d["lam"]), "nonneg": lambda: bz.NormL1Nonneg(d["lam"]),
+             "l1box": lambda: bz.NormL1Box(d["lam"], u=0.25 + u6(6)), "indbox": lambda: bz.IndBox(-0.5, 0.5),
+             "indboxvec": lambda: bz.IndBox(-(0.2 + 0.8 * u6(7)), 0.2 + 0.8 * u6(8))}[gk]()
+        D = {"box": lambda: bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])),
+             "boxvec": lambda: bz.ClosedSet(bz.IndBox(-(0.1 + 0.9 * u6(9)), 0.1 + 0.9 * u6(10))),
+             "boxveclo": lambda: bz.ClosedSet(bz.IndBox(-(0.1 + 0.9 * u6(9)), np.inf)),
+             "free": lambda: bz.FreeSet(), "zero": lambda: bz.ZeroSet(),
+             "vc": lambda: bz.PairwiseSet("vc"), "cc": lambda: bz.PairwiseSet("cc"),
+             "eitheror": lambda: bz.PairwiseSet("eitheror"), "xor": lambda: bz.PairwiseSet("xor")}[dk]()
+        return f, g, bz.IdentityFunction(), D
+
     def make_problem(c, po=None, mu=None, y=None):
-        p = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
-                       bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), nl, nl, np.float64, c)
+        p = bz.Problem(*family_oracles(), nl, nl, np.float64, c)
         p.set_multipliers(np.full(nl, 0.1) if mu is None else mu, np.zeros(nl) if y is None else y)
         p.panoc_begin(po or popts, np.zeros(nl))
         return p
@@ -755,8 +781,7 @@ def main():
                                   "ms_per_step": round(1e3 * r2["elapsed"] / args.steps, 5),
                                   "note": "directions=LBFGS(5) evaluated by the two-loop recursion in the reference's operation "
                                           "order (persistent register-resident kernel); same iterates up to rounding"}
-        out3 = bz.alps(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
-                       bz.ClosedSet(bz.IndBox(d["lo"], d["hi"])), np.zeros(nl), np.zeros(nl), maxit=2, ctx=ctx)
+        out3 = bz.alps(*family_oracles(), np.zeros(nl), np.zeros(nl), maxit=2, ctx=ctx)
         p3 = make_problem(ctx, None, out3[9], out3[1])
         r3 = timed_run(p3, args.steps, args.warmup)
         p3.close()
@@ -779,18 +804,22 @@ def main():
         # unless they travel as numbers) in, x_d out = 9..11 passes; 18..20 with stored pairs; the two-loop path:
         # k_twoloop_persist 4m passes + k_fused_sep 13)
         prof2 = R["prof2"]
-        roof, moved_iter = roofline_of(prof2, ALG, args.workload, nl, args.steps)
+        roof, moved_iter = roofline_of(prof2, ALG, args.workload if headline else args.workload + ":" + args.family, nl, args.steps)
         # the reference's dataflow: 65 passes per iteration on this workload at m = 5 — a model of
         # what the reference moves, reported as a ratio, never as a roofline fraction
         ref_iter = algorithmic_bytes_per_iter(nl, m=max(1, m), n_al=2, n_fb=1)
         out = {
-            "metric": "PANOC inner iterations/sec, n=10^7 l1-quadratic" if n == 10_000_000 else "PANOC inner iterations/sec, n=%d l1-quadratic" % n,
+            "metric": ("PANOC inner iterations/sec, n=10^7 l1-quadratic" if n == 10_000_000 else "PANOC inner iterations/sec, n=%d l1-quadratic" % n)
+            + ("" if headline else " (family %s)" % args.family),
             "value": round(its, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": args.workload + ": l1-regularised diagonal quadratic, n=%d fp64, soft-threshold prox_g, "
-                                   "c=Identity, D=Box[-1,1], LBFGS(5), mu=0.1, y=0, tol=0" % n,
+            "config": {"workload": (args.workload + ": l1-regularised diagonal quadratic, n=%d fp64, soft-threshold prox_g, "
+                                    "c=Identity, D=Box[-1,1], LBFGS(5), mu=0.1, y=0, tol=0" % n) if headline else
+                       (args.workload + " with the oracle family f-g-D = %s, n=%d fp64, c=Identity, LBFGS(5), mu=0.1, y=0, tol=0"
+                        % (args.family, n)),
+                       "family": args.family,
                        "n": n, "n_per_gpu": nl, "lbfgs_memory": M_LBFGS,
                        "parallelism": "single GPU" if world == 1 else
                        f"x sharded over {world} GPUs, scalars exchanged by " +
@@ -827,7 +856,7 @@ def main():
             out["rccl_value"] = rccl_extra["value"]
             out["rccl"] = rccl_extra
         out.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and headline:
             # bounded sample: ~10-30 s of CPU work whatever the size (the port runs ~2.5 it/s per 1e7 elements)
             states = max(4, int(round((args.cpu_states - 1) * min(1.0, 1.0e7 / n))) + 1)
             out["cpu_baseline"] = cpu_baseline(n, states)

@@ -66,7 +66,7 @@ class PanocOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("maxit", C.c_int64), ("freq", C.c_int32), ("verbose", C.c_int32),
                 ("minimum_gamma", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("max_backtracks", C.c_int32), ("lbfgs_memory", C.c_int32), ("fuse", C.c_int32),
-                ("persist", C.c_int32), ("lbfgs_compact", C.c_int32), ("reserved", C.c_int32)]
+                ("persist", C.c_int32), ("lbfgs_compact", C.c_int32), ("affine_refresh", C.c_int32)]
 
 
 class PanocStats(C.Structure):
@@ -75,7 +75,7 @@ class PanocStats(C.Structure):
                 ("n_grad", C.c_int64), ("n_prox", C.c_int64), ("n_backtracks", C.c_int64),
                 ("n_gamma_halvings", C.c_int64), ("n_fused_iters", C.c_int64),
                 ("n_lbfgs_skips", C.c_int64), ("elapsed_s", C.c_double), ("status", C.c_int32),
-                ("persist_fallbacks", C.c_int32)]
+                ("persist_fallbacks", C.c_int32), ("n_affine_images", C.c_int64)]
 
 
 class AlpsOpts(C.Structure):

@@ -2144,6 +2144,59 @@ k_gram_pair(CompactVecs<T, MM> V, const T* __restrict__ y_new, int64_t n, double
     block_reduce_store<2 * MM>(acc, 0u, parts, slot0);
 }
 
+// Affine images.  When c is affine (c(x) = A x - b), D is a subspace (ZeroSet / FreeSet: yupd = (c(x) + mu*y [- 0])/mu
+// is affine in x) and f is at most quadratic with a diagonal Hessian, BOTH c(x) and grad L(x) are affine maps of x.
+// The trial point x_d = x + d is an affine combination of points whose images are known — d = H0 (z - x) + sum u1_i s_i
+// + sum u2h_i y_i with s_i, y_i differences of earlier iterates / residuals — so its images are the same combination of
+// the stored images: no pass over A.  (demo/basispursuit.jl:38-49)
+//   out = base + H0 (zimg - base) + sum u1_i S[i] + sum u2h_i Y[i]       (compact_d's order of operations)
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_affine_image(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ base, const T* __restrict__ zimg,
+               T* __restrict__ out, int64_t len) {
+    T u1[MM], u2h[MM];
+    compact_coefs<T, MM>(C, u1, u2h);
+    const T H0 = (T)C.H0;
+    bz_for_chunks<T>(len, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        Pack<T> pb = ld(base, i0, cnt), pz = ld(zimg, i0, cnt), ps[MM], py[MM], o;
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+            if (i < V.m) { ps[i] = ld(V.S[i], i0, cnt); py[i] = ld(V.Y[i], i0, cnt); }
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T a = H0 * (pz.v[e] - pb.v[e]);
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < V.m) a = mul_add(u1[i], ps[i].v[e], a);
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < V.m) a = mul_add(u2h[i], py[i].v[e], a);
+            o.v[e] = pb.v[e] + a;
+        }
+        st(out, i0, cnt, o);
+    });
+}
+
+// images of the candidate pair: s_img = xnew - xold ; y_img = (xnew - znew) - (xold - zold)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_image_pair(const T* __restrict__ xnew, const T* __restrict__ xold, const T* __restrict__ znew,
+             const T* __restrict__ zold, T* __restrict__ s_img, T* __restrict__ y_img, int64_t len) {
+    bz_for_chunks<T>(len, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        Pack<T> a = ld(xnew, i0, cnt), b = ld(xold, i0, cnt), c = ld(znew, i0, cnt), d = ld(zold, i0, cnt), s, y;
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            s.v[e] = a.v[e] - b.v[e];
+            const T rn = a.v[e] - c.v[e], ro = b.v[e] - d.v[e];
+            y.v[e] = rn - ro;
+        }
+        st(s_img, i0, cnt, s);
+        st(y_img, i0, cnt, y);
+    });
+}
+
 // history as iterates -> history as pairs: S[i] = XH[i+1] - XH[i], Y[i] = RH[i+1] - RH[i] for the MM stored pairs
 // (run when an iteration leaves the plain path and the classic kernels need the difference vectors)
 template <class T, int MM> struct SnapVecs {

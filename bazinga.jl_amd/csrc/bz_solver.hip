@@ -226,6 +226,11 @@ template <class T> class Solver final : public SolverBase {
             GT_.alloc((size_t)nrowchunks * npad);
             x_replicated = ctx->nranks > 1;
             if (x_replicated) JL_.alloc(npad);
+            affine_ok_ = !x_replicated && !slack && (d.D_kind == BZ_D_ZERO || d.D_kind == BZ_D_FREE) &&
+                         (d.f_kind == BZ_F_ZERO || d.f_kind == BZ_F_DIAG_QUADRATIC);
+            if (affine_ok_) {
+                CXS_.alloc(ny); CZS_.alloc(ny); CXD_.alloc(ny); CZN_.alloc(ny);
+            }
         }
 
         std::memset(&P, 0, sizeof(P));
@@ -274,6 +279,7 @@ template <class T> class Solver final : public SolverBase {
         for (auto& b : RES_) b.alloc(vcap);
         for (auto& b : Z_) b.alloc(vcap);
         GX_.alloc(vcap); GZ_.alloc(vcap); D_.alloc(vcap); TMP_.alloc(vcap);
+        if (affine_ok_) { GXN_.alloc(vcap); GZN_.alloc(vcap); }
         parts_.alloc((size_t)SL_COUNT * PSTRIDE);
         BZ_HIP(hipMemsetAsync(parts_.p, 0, (size_t)SL_COUNT * PSTRIDE * sizeof(double), ctx->stream));
         alphas_.alloc(MAX_MEM + 1);
@@ -721,6 +727,28 @@ template <class T> class Solver final : public SolverBase {
     int64_t vcap = 0;                        // allocated elements per n-vector (>= n, zero-padded)
     bool persist_ok = false;
     bool stencil_fast_ = false;              // Stencil5pt f with the two fused stencil passes (see step())
+    // Affine images (dense affine c, D = ZeroSet / FreeSet, f = Zero / DiagQuadratic: c(.) and grad L(.) are affine maps):
+    // the images of the trial point x + d are formed from the stored images of the iterates — the same linear
+    // combination that forms d — instead of two passes over A; a pass-over-A evaluation every `aff_refresh_`
+    // iterations stops rounding drift.  State: c and grad L at the current x and z (CXS_, GX_, CZS_, GZ_), their
+    // candidates (CXD_, CZN_, GXN_, GZN_) and the images of every stored pair (AS_, AY_: ny-vectors; GS_, GY_: n).
+    bool affine_ok_ = false, aff_track_ = false;
+    int aff_refresh_ = 8, aff_count_ = 0;
+    int64_t n_affine_ = 0;
+    T* cx_keep_ = nullptr;                   // algrad (dense c): also leave c(point) here
+    DBuf<T> CXS_, CZS_, CXD_, CZN_, GXN_, GZN_;
+    std::vector<DBuf<T>> AS_, AY_, GS_, GY_;
+    CompactVecs<T, CM> image_vecs(bool ny_space) const {      // logical (oldest first) view, as compact_vecs()
+        CompactVecs<T, CM> V;
+        std::memset(&V, 0, sizeof(V));
+        V.m = (int)order.size();
+        for (int i = 0; i < V.m; ++i) {
+            const int s = order[V.m - 1 - i];
+            V.S[i] = ny_space ? AS_[s].p : GS_[s].p;
+            V.Y[i] = ny_space ? AY_[s].p : GY_[s].p;
+        }
+        return V;
+    }
     bool persist_broken_ = false;            // a grid barrier timed out once on this problem: the kernel chain from then on
     bool persist_sabotage_ = false;          // BZ_TEST_PERSIST_TIMEOUT=1: make the barrier miss its target (tests the fallback)
     std::vector<DBuf<T>> S_, Y_;
@@ -1274,6 +1302,7 @@ template <class T> class Solver final : public SolverBase {
         if (generic_) { algrad_generic(x, grad, slot0); return; }
         if (desc.c_kind == BZ_C_DENSE_AFFINE) {
             eval_c(x);                                                        // cx = A x - b
+            if (cx_keep_) BZ_HIP(hipMemcpyAsync(cx_keep_, CX_.p, ny * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
             mv(2 + pstreams(false, true, false), ny);
             launch(C_MISC, k_yupd<T>, grid_y, (const T*)CX_.p, P, YU_.p, ny, parts_.p, slot0 + 1);
             slot_n[slot0] = grid; slot_n[slot0 + 1] = grid_y;
@@ -1421,6 +1450,11 @@ template <class T> class Solver final : public SolverBase {
         S_ = std::vector<DBuf<T>>(M + 1);
         Y_ = std::vector<DBuf<T>>(M + 1);
         for (int i = 0; i <= M; ++i) { S_[i].alloc(vcap); Y_[i].alloc(vcap); }
+        if (affine_ok_) {
+            AS_ = std::vector<DBuf<T>>(M + 1); AY_ = std::vector<DBuf<T>>(M + 1);
+            GS_ = std::vector<DBuf<T>>(M + 1); GY_ = std::vector<DBuf<T>>(M + 1);
+            for (int i = 0; i <= M; ++i) { AS_[i].alloc(ny); AY_[i].alloc(ny); GS_[i].alloc(vcap); GY_[i].alloc(vcap); }
+        }
     }
     void lbfgs_reset_all() {
         gm = 0; pw_valid = false;
@@ -1686,7 +1720,14 @@ template <class T> class Solver final : public SolverBase {
         // (... and the stencil path: x_d, k_stencil_fb, k_stencil_update_c with ONE reduction phase per iteration
         // instead of the persistent two-loop kernel's 2m - 1 grid barriers, or 2m + 1 exchanges when sharded)
         stencil_fast_ = desc.f_kind == BZ_F_STENCIL5 && o.fuse && !lp_g && !slack;
-        compact_ok = M >= 1 && (o.lbfgs_compact == 1 || (o.lbfgs_compact == 2 && (fused_ok || stencil_fast_) && M <= CM));
+        if (o.affine_refresh < 0) throw Error(BZ_ERR_ARG, "affine_refresh must be >= 0");
+        aff_refresh_ = o.affine_refresh;
+        static const int aff_env = std::getenv("BZ_AFFINE") ? std::atoi(std::getenv("BZ_AFFINE")) : -1;
+        if (aff_env >= 0) aff_refresh_ = aff_env;
+        aff_track_ = affine_ok_ && aff_refresh_ > 0 && o.lbfgs_compact != 0 && M >= 1 && M <= CM;
+        aff_count_ = 0; n_affine_ = 0;
+        compact_ok = M >= 1 && (o.lbfgs_compact == 1 ||
+                                (o.lbfgs_compact == 2 && (fused_ok || stencil_fast_ || aff_track_) && M <= CM));
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
             // block per CU) and the vector must be long enough for 2m-1 grid barriers to beat 2m launches
@@ -1733,7 +1774,9 @@ template <class T> class Solver final : public SolverBase {
             gather(SL_FXD, 2, 0u);
             n_grad += 2; gx_valid = true;
         } else {
+            if (aff_track_) cx_keep_ = CXS_.p;
             algrad(x, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+            cx_keep_ = nullptr;
             // gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad_f_x)
             mv(2);
             launch(C_MISC, k_add_scalar<T>, grid, (const T*)x, T(1), TMP_.p, n);
@@ -1771,7 +1814,9 @@ template <class T> class Solver final : public SolverBase {
                 fbstep(x, GX_.p, gamma, Z_[zc].p, RES_[rc].p, SL_GSUM);
                 gather(SL_GSUM, 3, 0u);
                 ++n_prox;
+                if (aff_track_) cx_keep_ = CZS_.p;
                 algrad(Z_[zc].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
+                cx_keep_ = nullptr;
                 v = collect({SL_GSUM, SL_DOT, SL_SS, SL_FZ, SL_PZ}, 0u);
             }
             g_z = g_value(v[0]); dot_gr = T(v[1]); ss_res = T(v[2]);
@@ -1864,7 +1909,7 @@ template <class T> class Solver final : public SolverBase {
         // (headline family: the one-pass kernel also serves an EMPTY memory — d = H0 (-res), all coefficients zero —
         // so the first iteration of a solve is a 3..5-stream pass too instead of k_fused_sep's 12)
         const bool use_compact = compact_ok && (!order.empty() || (fused_ok && fused_family() >= 0) ||
-                                                (stencil_fast_ && !ctx->multi()));
+                                                (stencil_fast_ && !ctx->multi()) || aff_track_);
         const bool use_persist = persist_ok && !order.empty() && !use_compact;
         CompactVecs<T, CM> CV;
         CompactCoef<CM> CC;
@@ -2078,6 +2123,29 @@ template <class T> class Solver final : public SolverBase {
                 }
                 have_trial = true; gx_valid = true; gz_valid = false;
                 n_grad += 2; n_prox += 1;
+            } else if (aff_track_) {
+                // gradient (and c) at x_d into the candidate buffers, then trade: GX_ = grad L(x_d), GXN_ = grad L(x_prev)
+                if (use_compact && gx_valid && gz_valid && aff_count_ + 1 < aff_refresh_) {
+                    ++aff_count_; ++n_affine_;
+                    CompactVecs<T, CM> VA = image_vecs(true), VG = image_vecs(false);
+                    mv(2 * VA.m + 3, ny); nm("k_affine_image");
+                    launch(C_MISC, k_affine_image<T, CM>, grid_y, VA, CC, (const T*)CXS_.p, (const T*)CZS_.p, CXD_.p, ny);
+                    mv(2 * VG.m + 3);
+                    launch(C_MISC, k_affine_image<T, CM>, grid, VG, CC, (const T*)GX_.p, (const T*)GZ_.p, GXN_.p, n);
+                    // the value L(x_d): f element-wise, the penalty from the image of c
+                    slot_n[SL_FXD] = grid; slot_n[SL_PXD] = grid_y;
+                    mv(1 + pstreams(true, false, false));
+                    launch(C_MISC, k_fvalue_elem<T>, grid, (const T*)X_[xd].p, P, n, parts_.p, (int)SL_FXD, (const T*)nullptr);
+                    mv(2 + pstreams(false, true, false), ny);
+                    launch(C_MISC, k_yupd<T>, grid_y, (const T*)CXD_.p, P, YU_.p, ny, parts_.p, (int)SL_PXD);
+                } else {
+                    aff_count_ = 0;
+                    cx_keep_ = CXD_.p;
+                    algrad(X_[xd].p, GXN_.p, SL_FXD);
+                    cx_keep_ = nullptr;
+                }
+                std::swap(GX_.p, GXN_.p); std::swap(GX_.n, GXN_.n);
+                ++n_grad; gx_valid = true;
             } else {
                 algrad(X_[xd].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
             }
@@ -2093,13 +2161,25 @@ template <class T> class Solver final : public SolverBase {
                 fbstep(X_[xcur].p, GX_.p, gamma, Z_[zn].p, RES_[rn].p, SL_GSUM);
                 gather(SL_GSUM, 3, 0u);
                 ++n_prox;
-                algrad(Z_[zn].p, GZ_.p, SL_FZ); ++n_grad; gz_valid = true;
+                T* const gz_dst = aff_track_ ? GZN_.p : GZ_.p;      // (affine images: grad L(z_prev) is still needed)
+                if (aff_track_) cx_keep_ = CZN_.p;
+                algrad(Z_[zn].p, gz_dst, SL_FZ); ++n_grad; gz_valid = true;
+                cx_keep_ = nullptr;
                 for (int kk = 0; kk < 3; ++kk) slot_n[SL_YS + kk] = grid;
                 mv(8);
                 launch(C_UPDATE, k_update<T>, grid, (const T*)X_[xcur].p, (const T*)X_[xp].p,
-                       (const T*)RES_[rn].p, (const T*)RES_[rp].p, (const T*)GX_.p, (const T*)GZ_.p, gamma,
+                       (const T*)RES_[rn].p, (const T*)RES_[rp].p, (const T*)GX_.p, (const T*)gz_dst, gamma,
                        S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_YS);
                 gather(SL_YS, 3, 4u);
+                if (aff_track_) {
+                    // images of the candidate pair (s = x - x_prev, y = res - res_prev) under c and grad L
+                    mv(6, ny);
+                    launch(C_MISC, k_image_pair<T>, grid_y, (const T*)CXD_.p, (const T*)CXS_.p, (const T*)CZN_.p,
+                           (const T*)CZS_.p, AS_[spare].p, AY_[spare].p, ny);
+                    mv(6);
+                    launch(C_MISC, k_image_pair<T>, grid, (const T*)GX_.p, (const T*)GXN_.p, (const T*)GZN_.p,
+                           (const T*)GZ_.p, GS_[spare].p, GY_[spare].p, n);
+                }
             }
             if (have_trial && gram_from_trial) {
                 v = tail_used ? wait_host(NFC, tail_ticket) : collect_range(SL_TRIAL, NFC, 1u << 9);
@@ -2184,8 +2264,16 @@ template <class T> class Solver final : public SolverBase {
                 have_trial = true; gram_from_trial = true; gx_valid = false; gz_valid = false;
                 n_grad += 2; n_prox += 1;
             } else {
+                if (aff_track_) { cx_keep_ = CXD_.p; aff_count_ = 0; }
                 algrad(X_[xb].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+                cx_keep_ = nullptr;
             }
+        }
+        if (aff_track_) {
+            // the accepted state's images become the current ones
+            std::swap(GZ_.p, GZN_.p); std::swap(GZ_.n, GZN_.n);
+            std::swap(CZS_.p, CZN_.p); std::swap(CZS_.n, CZN_.n);
+            std::swap(CXS_.p, CXD_.p); std::swap(CXS_.n, CXD_.n);
         }
         // update!(H, x - x_prev, res - res_prev): the pair sits in the spare slot
         const T ys = T(v[7]), yty = T(v[8]);
@@ -2254,6 +2342,7 @@ template <class T> class Solver final : public SolverBase {
         st->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         st->status = std::isnan((double)f_x) ? 2 : ((double)stop_norm_ <= opt.tol ? 0 : 1);
         st->persist_fallbacks = (int32_t)n_persist_fallbacks_;
+        st->n_affine_images = n_affine_;
     }
 };
 

@@ -145,13 +145,16 @@ class PANOCplus:
 
     def __init__(self, *, directions=None, maxit=1000, tol=1e-8, verbose=False, freq=10,
                  minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, persist=True,
-                 ctx=None):
+                 affine_refresh=8, ctx=None):
         self.directions = directions if directions is not None else LBFGS(5)
         if not isinstance(self.directions, (LBFGS, NoAcceleration)):
             raise UnsupportedOracle("only directions=LBFGS(M) and NoAcceleration() are lowered to the device")
         self.maxit, self.tol, self.verbose, self.freq = maxit, tol, verbose, freq
         self.minimum_gamma, self.alpha, self.beta = minimum_gamma, alpha, beta
         self.max_backtracks, self.fuse, self.persist, self.ctx = max_backtracks, fuse, persist, ctx
+        # affine images (bz_panoc_opts.affine_refresh): dense affine c with D = ZeroSet / FreeSet — 0 off, k >= 1: a
+        # pass-over-A evaluation of the trial point's gradient every k-th iteration, images in between
+        self.affine_refresh = int(affine_refresh)
         self.stats = None
 
     def c_opts(self) -> L.PanocOpts:
@@ -162,6 +165,7 @@ class PANOCplus:
         o.minimum_gamma, o.alpha, o.beta = float(self.minimum_gamma), float(self.alpha), float(self.beta)
         o.max_backtracks, o.lbfgs_memory, o.fuse = int(self.max_backtracks), self.directions.memory, int(bool(self.fuse))
         o.persist = int(bool(self.persist))
+        o.affine_refresh = self.affine_refresh
         cm = getattr(self.directions, "compact", None)
         o.lbfgs_compact = 2 if cm is None else int(bool(cm))
         return o

@@ -231,7 +231,14 @@ typedef struct {
                                    alternate rounding: its iterates track the fp64 oracle as closely as the
                                    two-loop kernels' do;
                                 2 (default): 1 where that one-pass kernel applies, 0 elsewhere.         */
-    int32_t reserved;
+    int32_t affine_refresh;  /* affine images (c = DenseAffine, D = ZeroSet / FreeSet, f = Zero / DiagQuadratic:
+                                c(.) and grad L(.) are affine maps).  k >= 1 (default 8): c(x + d) and grad L(x + d)
+                                are formed from the stored images of the iterates — the linear combination that
+                                forms d, applied to their images: no pass over A — and evaluated with the two passes
+                                over A every k-th iteration, which bounds the rounding drift; with it an iteration
+                                reads A twice instead of four times.  1: every evaluation passes over A (no images
+                                used); 0: no image bookkeeping at all (the reference's dataflow).  Needs the compact
+                                L-BFGS form (lbfgs_compact != 0, lbfgs_memory <= 5).                          */
 } bz_panoc_opts;
 
 void bz_panoc_default_opts(bz_panoc_opts* o);
@@ -255,6 +262,7 @@ typedef struct {
     int32_t status;           /* 0 converged, 1 maxit, 2 NaN encountered              */
     int32_t persist_fallbacks;/* times the persistent two-loop kernel's grid barrier timed out (its workgroups
                                  were not co-resident) and the solve went on with the kernel chain (0 or 1)   */
+    int64_t n_affine_images;  /* AL gradients formed from stored images instead of two passes over A          */
 } bz_panoc_stats;
 
 /* Multipliers/penalties of the current subproblem:  AugLagUpdate!(alFun, mu, y)

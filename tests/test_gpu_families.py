@@ -140,8 +140,8 @@ def test_family_forms_are_bitwise_neutral(bz, ref, fam):
     y0 = np.zeros(n)
     u0 = _run(bz, dev, n, mu, y0, x0, 40, dict(pin, BZ_XR="2", BZ_UNI="0"))
     u2 = _run(bz, dev, n, mu, y0, x0, 40, dict(pin, BZ_XR="2", BZ_UNI="2"))
-    for a, b in zip(u0[:3], u2[:3]):
-        assert np.array_equal(a, b)
+    for a, b in zip(u0[:3], u2[:3]):      # (f = Zero with y = 0 can start on a flat piece: gamma = alpha / 0, NaN in both)
+        assert np.array_equal(a, b, equal_nan=True)
     # the generic kernel chain (fuse = False) on the same grid: same values (p, w come from another kernel's sums)
     g = _run(bz, dev, n, mu, y, x0, 25, dict(pin), fuse=False, compact=True)
     f = _run(bz, dev, n, mu, y, x0, 25, dict(pin, BZ_XR="2"))

@@ -133,13 +133,14 @@ def _err(a, b):
 
 
 def run_traces(bz, ref, dev, orc, n, mu, y, x0, iters, fuse=True, minimum_gamma=1e-7, dtype=np.float64,
-               ny=None, compact=None):
+               ny=None, compact=None, affine_refresh=8):
     """Step the device solver and the oracle side by side.  Returns rows
     (k, err_x, err_z, gamma_dev, gamma_ref, stop_dev, stop_ref, fused, self_sensitivity)."""
     ny = n if ny is None else ny
     prob = bz.Problem(*dev, n, ny, dtype)
     prob.set_multipliers(mu, y)
-    sub = bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=minimum_gamma, fuse=fuse, directions=bz.LBFGS(5, compact=compact))
+    sub = bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=minimum_gamma, fuse=fuse, directions=bz.LBFGS(5, compact=compact),
+                       affine_refresh=affine_refresh)
     prob.panoc_begin(sub.c_opts(), x0)
     its, sts = [], []
     for red in (None, LongDoubleReducer()):
@@ -420,14 +421,18 @@ def test_stencil_al_gradient_bit_exact(bz, ref, shape):
     prob.close()
 
 
+@pytest.mark.parametrize("form", ["default", "two-loop"])
 @pytest.mark.parametrize("shape,iters", [((16, 32), 40), ((200, 128), 25), ((2048, 2048), 8)])
-def test_stencil_panoc_iterates_match_oracle(bz, ref, shape, iters):
+def test_stencil_panoc_iterates_match_oracle(bz, ref, shape, iters, form):
+    """cfg 3 against the two-loop oracle, in the library default (compact representation: x_d, k_stencil_fb,
+    k_stencil_update_c — one reduction phase) and with the two-loop kernels (reference operation order)."""
     nx, ny = shape
     d, n, dev, orc = make_cfg3(bz, ref, nx, ny)
     mu = np.full(n, 0.1)
     y = np.zeros(n)
     prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, d["x0"].copy(), iters,
-                                minimum_gamma=float(np.finfo(float).eps))
+                                minimum_gamma=float(np.finfo(float).eps), compact=None if form == "default" else False)
+    p2 = prob.profile2()
     for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
         assert abs(g_d - g_r) <= 1e-13 * g_r
         # ill-conditioned Laplacian + active-set changes: errors of ANY two roundings grow
@@ -436,6 +441,22 @@ def test_stencil_panoc_iterates_match_oracle(bz, ref, shape, iters):
         if k <= 12:
             assert ex <= RTOL_ITER and ez <= RTOL_ITER
     prob.close()
+
+
+def test_stencil_compact_form_is_the_default_and_runs_without_the_persistent_kernel(bz, ref):
+    nx, ny = 1024, 1024
+    d, n, dev, orc = make_cfg3(bz, ref, nx, ny)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), d["x0"])
+    prob.profile_enable(True)
+    for _ in range(12):
+        prob.panoc_step()
+    p = prob.profile2()
+    prob.close()
+    assert p["k_twoloop_persist"]["launches"] == 0 and p["k_axpy_dot"]["launches"] == 0
+    assert p["k_stencil_update"]["form"] == "k_stencil_update_c" and p["k_stencil_update"]["launches"] >= 11
+    assert p["x_d"]["form"] == "k_compact_xd"
 
 
 def test_stencil_alps_small_obstacle(bz, ref):
@@ -746,16 +767,19 @@ def test_no_acceleration_direction(bz, ref):
     prob.close()
 
 
-def test_stencil_fast_path_equals_generic_bitwise(bz, ref):
-    """cfg 3: the two fused stencil passes ({gradL(x_d) + FB step}, {gradL(z) + pair + stop norm}) are the
-    same arithmetic and the same summation order as the four generic kernels."""
+@pytest.mark.parametrize("compact", [False, True])
+def test_stencil_fast_path_equals_generic_bitwise(bz, ref, compact):
+    """cfg 3: the two fused stencil passes ({gradL(x_d) + FB step}, {gradL(z) + pair + stop norm [+ the compact
+    form's Gram products and next p, w: k_stencil_update_c]}) are the same arithmetic and the same summation order
+    as the generic kernels they replace, in both forms of the L-BFGS operator."""
     nx, ny = 96, 128
     d, n, dev, orc = make_cfg3(bz, ref, nx, ny, load=-1.0)
     out = []
     for fuse in (True, False):
         prob = bz.Problem(*dev, n, n, np.float64)
         prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
-        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse, minimum_gamma=2.3e-16).c_opts(), d["x0"])
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse, minimum_gamma=2.3e-16,
+                                      directions=bz.LBFGS(5, compact=compact)).c_opts(), d["x0"])
         for _ in range(30):
             prob.panoc_step()
         out.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars()))

@@ -12,6 +12,15 @@ from tests.test_gpu_parity import make_cfg4, rel, run_traces
 
 pytestmark = pytest.mark.gpu
 
+_FULL = {}
+
+
+def full_size_cfg4(bz, ref):
+    """the 2 GiB matrix is generated once per session (splitmix64 in numpy: ~1 min)"""
+    if "d" not in _FULL:
+        _FULL["d"] = make_cfg4(bz, ref, 8192, 65536, np.float32, density=0.01)
+    return _FULL["d"]
+
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(64, 512), (257, 1028)])
@@ -86,7 +95,7 @@ def test_dense_full_size_iterates_fp32(bz, ref, refresh):
     fp32, the MFMA transposed product in the loop — with the affine images (default) and with
     every gradient evaluated by passes over A."""
     ny, n = 8192, 65536
-    d, dev, orc = make_cfg4(bz, ref, ny, n, np.float32, density=0.01)
+    d, dev, orc = full_size_cfg4(bz, ref)
     mu, y, x0 = np.full(ny, 0.1, np.float32), np.zeros(ny, np.float32), np.zeros(n, np.float32)
     prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 8, minimum_gamma=float(np.finfo(np.float32).eps),
                                 dtype=np.float32, ny=ny, affine_refresh=refresh)

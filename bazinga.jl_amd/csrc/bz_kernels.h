@@ -2366,8 +2366,9 @@ k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T>
 constexpr int FAM_F_ZERO = 0, FAM_F_DIAG = 1;
 constexpr int FAM_G_ZERO = 0, FAM_G_L1 = 1, FAM_G_L1NONNEG = 2, FAM_G_L1BOX = 3, FAM_G_INDBOX = 4, FAM_G_INDBOX_VEC = 5;
 constexpr int FAM_G_COUNT = 6;
-constexpr int FAM_D_ZERO = 0, FAM_D_FREE = 1, FAM_D_BOX = 2, FAM_D_BOX_VEC = 3, FAM_D_PAIRS = 4;
-constexpr int FAM_D_COUNT = 5;
+constexpr int FAM_D_ZERO = 0, FAM_D_FREE = 1, FAM_D_BOX = 2, FAM_D_BOX_VEC = 3;
+constexpr int FAM_D_VC = 4, FAM_D_CC = 5, FAM_D_EITHEROR = 6, FAM_D_XOR = 7;      // BZ_D_VC_PAIRS + (k - 4): one kind per
+constexpr int FAM_D_COUNT = 8;      // instantiation (all four in one kernel is 13 000 instructions: past the instruction cache)
 constexpr int fam_code(int fk, int gk, int dk) { return fk | (gk << 1) | (dk << 4); }
 constexpr int fam_fk(int fam) { return fam & 1; }
 constexpr int fam_gk(int fam) { return (fam >> 1) & 7; }
@@ -2391,7 +2392,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     constexpr int GKC = fam_gk(FAM), DKC = fam_dk(FAM);
     const int fk = FAMILY ? fam_fk(FAM) : (SPEC ? (int)BZ_F_DIAG_QUADRATIC : P.f_kind);
     const int gk = FAMILY ? (GKC >= FAM_G_INDBOX ? (int)BZ_G_IND_BOX : GKC) : (SPEC ? (int)BZ_G_NORM_L1 : P.g_kind);
-    const int dk = FAMILY ? (DKC == FAM_D_PAIRS ? P.D_kind : (DKC >= FAM_D_BOX ? (int)BZ_D_BOX : DKC))
+    const int dk = FAMILY ? (DKC >= FAM_D_VC ? (int)BZ_D_VC_PAIRS + (DKC - FAM_D_VC) : (DKC >= FAM_D_BOX ? (int)BZ_D_BOX : DKC))
                           : (SPEC ? (int)BZ_D_BOX : P.D_kind);
     const int uni = UNI >= 0 ? UNI : C.uni_rt;
     const bool trial = TRIAL >= 0 ? (TRIAL != 0) : (C.trial_rt != 0);

@@ -1438,7 +1438,11 @@ template <class T> class Solver final : public SolverBase {
         case BZ_D_ZERO: dk = FAM_D_ZERO; break;
         case BZ_D_FREE: dk = FAM_D_FREE; break;
         case BZ_D_BOX: dk = (P.D_lo_vec || P.D_hi_vec) ? FAM_D_BOX_VEC : FAM_D_BOX; break;
-        default: dk = FAM_D_PAIRS; break;
+        case BZ_D_VC_PAIRS: dk = FAM_D_VC; break;
+        case BZ_D_CC_PAIRS: dk = FAM_D_CC; break;
+        case BZ_D_EITHEROR_PAIRS: dk = FAM_D_EITHEROR; break;
+        case BZ_D_XOR_PAIRS: dk = FAM_D_XOR; break;
+        default: return -1;
         }
         return fam_code(fk, gk, dk);
     }
@@ -2354,7 +2358,10 @@ template <class T> FusedFn<T> family_kernel(int fam, bool nt) {
     case FAM_D_FREE: return family_kernel_dk<T, FAM_D_FREE>(fam, nt);
     case FAM_D_BOX: return family_kernel_dk<T, FAM_D_BOX>(fam, nt);
     case FAM_D_BOX_VEC: return family_kernel_dk<T, FAM_D_BOX_VEC>(fam, nt);
-    case FAM_D_PAIRS: return family_kernel_dk<T, FAM_D_PAIRS>(fam, nt);
+    case FAM_D_VC: return family_kernel_dk<T, FAM_D_VC>(fam, nt);
+    case FAM_D_CC: return family_kernel_dk<T, FAM_D_CC>(fam, nt);
+    case FAM_D_EITHEROR: return family_kernel_dk<T, FAM_D_EITHEROR>(fam, nt);
+    case FAM_D_XOR: return family_kernel_dk<T, FAM_D_XOR>(fam, nt);
     default: return nullptr;
     }
 }

@@ -211,6 +211,55 @@ def cpu_baseline_oracle(workload, orc, n, ny, dtype, mu, y, x0, minimum_gamma, b
             "julia_on_box": __import__("shutil").which("julia") is not None}
 
 
+def whole_alps_rates(bz, oracles, n, ctx):
+    """A whole Bazinga.alps solve of the workload (x0 = 0, y0 = 0, tol = 1e-6) through bz_alps_solve: inner
+    iterations per second over the WHOLE call (alps.jl:27,103,115: elapsed_time brackets everything), (a) with the
+    six n-vectors (x0, y0 in; x, y, s, mu out) in pageable host memory, as the Python / Julia hosts hand them over,
+    and (b) with device pointers, which the C ABI accepts as well (hipMemcpyDefault): nothing but scalars crosses PCIe."""
+    import ctypes as C
+    L = bz._lib
+    out = {}
+    prob = bz.Problem(*oracles, n, n, np.float64, ctx)
+    ao = L.AlpsOpts()
+    L.load().bz_alps_default_opts(C.byref(ao), L.BZ_F64)
+    po = bz.PANOCplus(tol=ao.inner_tol).c_opts()
+    x0, y0 = np.zeros(n), np.zeros(n)
+    for rep_i in range(2):      # (first call: page faults of fresh output arrays, lazy allocations)
+        t0 = time.perf_counter()
+        x, y, s, mu, st = prob.alps_solve(ao, po, x0, y0)
+        dt = time.perf_counter() - t0
+    out["host_pageable"] = {"ms": round(1e3 * dt, 3), "outer": int(st.tot_it), "inner": int(st.tot_inner_it),
+                            "value": round(st.tot_inner_it / dt, 2), "unit": "inner iterations/s"}
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        hip.hipFree.argtypes = [C.c_void_p]
+        bufs = []
+        for _ in range(6):
+            p = C.c_void_p()
+            if hip.hipMalloc(C.byref(p), n * 8) != 0:
+                raise RuntimeError("hipMalloc failed")
+            hip.hipMemset(p, 0, n * 8)
+            bufs.append(p)
+        hip.hipDeviceSynchronize()
+        st2 = L.AlpsStats()
+        for rep_i in range(2):
+            t0 = time.perf_counter()
+            L.check(L.load().bz_alps_solve(prob._h, C.byref(ao), C.byref(po), bufs[0], bufs[1], bufs[2], bufs[3], bufs[4],
+                                           bufs[5], C.byref(st2)))
+            dt2 = time.perf_counter() - t0
+        for p in bufs:
+            hip.hipFree(p)
+        out["device_pointers"] = {"ms": round(1e3 * dt2, 3), "outer": int(st2.tot_it), "inner": int(st2.tot_inner_it),
+                                  "value": round(st2.tot_inner_it / dt2, 2), "unit": "inner iterations/s"}
+        out["pcie_share_of_host_call"] = round(max(0.0, dt - dt2) / dt, 4)
+    except Exception as e:      # noqa: BLE001
+        out["device_pointers"] = {"value": None, "note": repr(e)[:200]}
+    prob.close()
+    return out
+
+
 class SocketGroup:
     """Minimal process group over TCP (star through rank 0) for the launcher-side plumbing of N > 1:
     all-gather of small byte strings, barrier, max/min reductions.  torch.distributed would do, but
@@ -782,6 +831,10 @@ def main():
                                   "note": "directions=LBFGS(5) evaluated by the two-loop recursion in the reference's operation "
                                           "order (persistent register-resident kernel); same iterates up to rounding"}
         out3 = bz.alps(*family_oracles(), np.zeros(nl), np.zeros(nl), maxit=2, ctx=ctx)
+        try:
+            extras["whole_alps"] = whole_alps_rates(bz, family_oracles(), nl, ctx)
+        except Exception as e:      # noqa: BLE001
+            extras["whole_alps"] = {"note": repr(e)[:200]}
         p3 = make_problem(ctx, None, out3[9], out3[1])
         r3 = timed_run(p3, args.steps, args.warmup)
         p3.close()

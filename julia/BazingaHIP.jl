@@ -1,8 +1,9 @@
 # BazingaHIP.jl — the reference-side binding a Bazinga.jl maintainer would add.
 #
-# NOT RUNNABLE IN THE BUILD CONTAINER (no `julia` there); written against include/bazinga_hip.h and kept
-# in sync with the ctypes binding bazinga.jl_amd/_lib.py, whose struct layouts ARE tested against the
-# header (tests/test_abi.py).
+# NOT EXECUTED — PARITY UNPINNED: there is no `julia` in the build container or on the GPU box, so this file has
+# never run.  It is written against include/bazinga_hip.h and kept in sync with the ctypes binding
+# bazinga.jl_amd/_lib.py, whose struct layouts ARE tested against the header (tests/test_abi.py) and which
+# exercises every entry point used here (tests/, -m gpu).
 #
 # Usage — nothing else in user code changes:
 #     using Bazinga, BazingaHIP
@@ -18,7 +19,7 @@ const lib = get(ENV, "BAZINGA_HIP_LIB", "libbazinga_hip.so")
 
 # ---- mirrors of the C structs (include/bazinga_hip.h) ----------------------------------------
 struct CtxOpts
-    device::Int32; rank::Int32; nranks::Int32; reserved::Int32; comm_id::Ptr{Cvoid}
+    device::Int32; rank::Int32; nranks::Int32; flags::Int32; comm_id::Ptr{Cvoid}      # flags: BZ_CTX_RUNTIME_TUNING = 1
 end
 Base.@kwdef mutable struct ProblemDesc
     dtype::Int32 = 0; f_kind::Int32 = 0; g_kind::Int32 = 0; c_kind::Int32 = 0; D_kind::Int32 = 0
@@ -30,18 +31,22 @@ Base.@kwdef mutable struct ProblemDesc
     g_lo_vec::Ptr{Cvoid} = C_NULL; g_hi_vec::Ptr{Cvoid} = C_NULL
     c_A::Ptr{Cvoid} = C_NULL; c_b::Ptr{Cvoid} = C_NULL
     D_lo::Float64 = 0; D_hi::Float64 = 0; D_lo_vec::Ptr{Cvoid} = C_NULL; D_hi_vec::Ptr{Cvoid} = C_NULL
+    # generic oracles (all four kinds BZ_*_CALLBACK): host callbacks, see lower_generic!
+    cb_user::Ptr{Cvoid} = C_NULL; cb_f_gradient::Ptr{Cvoid} = C_NULL; cb_g_prox::Ptr{Cvoid} = C_NULL
+    cb_c_eval::Ptr{Cvoid} = C_NULL; cb_c_jtprod::Ptr{Cvoid} = C_NULL; cb_D_proj::Ptr{Cvoid} = C_NULL
 end
 Base.@kwdef mutable struct PanocOpts
     tol::Float64 = 1e-8; maxit::Int64 = 1000; freq::Int32 = 10; verbose::Int32 = 0
     minimum_gamma::Float64 = 1e-7; alpha::Float64 = 0.95; beta::Float64 = 0.5
     max_backtracks::Int32 = 20; lbfgs_memory::Int32 = 5; fuse::Int32 = 1; persist::Int32 = 1
-    lbfgs_compact::Int32 = 2; reserved::Int32 = 0
+    lbfgs_compact::Int32 = 2; affine_refresh::Int32 = 8
 end
 Base.@kwdef mutable struct PanocStats
     iters::Int64 = 0; f_z::Float64 = 0; g_z::Float64 = 0; al_z::Float64 = 0; gamma::Float64 = 0
     tau::Float64 = 0; stop_norm::Float64 = 0; n_grad::Int64 = 0; n_prox::Int64 = 0
     n_backtracks::Int64 = 0; n_gamma_halvings::Int64 = 0; n_fused_iters::Int64 = 0
-    n_lbfgs_skips::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; reserved::Int32 = 0
+    n_lbfgs_skips::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; persist_fallbacks::Int32 = 0
+    n_affine_images::Int64 = 0
 end
 
 Base.@kwdef mutable struct AlpsOpts
@@ -96,16 +101,21 @@ end
 dtype_code(::Type{Float64}) = Int32(0)
 dtype_code(::Type{Float32}) = Int32(1)
 
-lower_f!(d, f::Bazinga.Zero) = (d.f_kind = 0)
-lower_f!(d, f::ProximalOperators.Zero) = (d.f_kind = 0)
-lower_f!(d, f::DiagQuadratic) = (d.f_kind = 1; d.f_q = pointer(f.q); d.f_b = pointer(f.b))
-lower_f!(d, f::Stencil5ptQuadratic) = (d.f_kind = 2; d.f_grid_nx = f.nx; d.f_grid_ny = f.ny; d.f_b = pointer(f.b))
+# Every lower_*! returns the temporaries whose memory the descriptor points into (or `nothing`): the Problem
+# constructor roots them with GC.@preserve until bz_problem_create has copied the data.
+lower_f!(d, f::Bazinga.Zero) = (d.f_kind = 0; nothing)
+lower_f!(d, f::ProximalOperators.Zero) = (d.f_kind = 0; nothing)
+lower_f!(d, f::DiagQuadratic) = (d.f_kind = 1; d.f_q = pointer(f.q); d.f_b = pointer(f.b); nothing)
+lower_f!(d, f::Stencil5ptQuadratic) = (d.f_kind = 2; d.f_grid_nx = f.nx; d.f_grid_ny = f.ny; d.f_b = pointer(f.b); nothing)
 # dense f: Julia matrices are column-major, the library wants row-major -> pass the transpose's memory
-lower_f!(d, f::ProximalOperators.LeastSquares) = (At = permutedims(f.A); d.f_kind = 3; d.f_A = pointer(At);
-                                                  d.f_rows = size(f.A, 1); d.f_b = pointer(f.b); At)
+function lower_f!(d, f::ProximalOperators.LeastSquares)
+    At = permutedims(f.A)
+    d.f_kind = 3; d.f_A = pointer(At); d.f_rows = size(f.A, 1); d.f_b = pointer(f.b)
+    return At                                                          # kept alive by the caller
+end
 lower_f!(d, f::ProximalOperators.Quadratic) = (d.f_kind = 4; d.f_A = pointer(f.Q); d.f_rows = size(f.Q, 1);
-                                               d.f_b = pointer(f.q))      # Q symmetric: layout-agnostic
-lower_f!(d, f) = error("BazingaHIP: f of type $(typeof(f)) is not lowered to the device")
+                                               d.f_b = pointer(f.q); nothing)      # Q symmetric: layout-agnostic
+lower_f!(d, f) = :generic
 
 lower_g!(d, g::Bazinga.Zero) = (d.g_kind = 0)
 lower_g!(d, g::ProximalOperators.Zero) = (d.g_kind = 0)
@@ -117,13 +127,13 @@ lower_g!(d, g::ProximalOperators.IndBox{<:Real,<:Real}) = (d.g_kind = 4; d.g_lo 
 lower_g!(d, g::Bazinga.NormL0Box) = (d.g_kind = 5; d.g_lambda = g.lambda; d.g_u = pointer(g.u))
 lower_g!(d, g::Bazinga.NormLpPowerNonneg) = (d.g_kind = 6; d.g_lambda = g.alpha; d.g_p = g.p)
 lower_g!(d, g::Bazinga.NormLpPowerBox) = (d.g_kind = 7; d.g_lambda = g.alpha; d.g_p = g.p; d.g_u = pointer(g.u))
-lower_g!(d, g) = error("BazingaHIP: g of type $(typeof(g)) is not lowered to the device")
+lower_g!(d, g) = :generic
 
 # c: any SmoothFunction whose eval!/jtprod! are the identity (e.g. test/definitions/identityFunction.jl)
 abstract type IdentityLike <: Bazinga.SmoothFunction end
 lower_c!(d, c::IdentityLike) = (d.c_kind = 0)
 lower_c!(d, c::DenseAffine) = (d.c_kind = 1; d.c_A = pointer(c.At); d.c_b = pointer(c.b))
-lower_c!(d, c) = error("BazingaHIP: c of type $(typeof(c)) is not lowered to the device")
+lower_c!(d, c) = :generic
 
 lower_D!(d, D::Bazinga.ZeroSet) = (d.D_kind = 0)
 lower_D!(d, D::Bazinga.FreeSet) = (d.D_kind = 1)
@@ -147,18 +157,59 @@ function Bazinga.proj!(z, D::PairwiseSet, x)
     return nothing
 end
 lower_D!(d, D::PairwiseSet) = (d.D_kind = Dict(:vc => 3, :cc => 4, :eitheror => 5, :xor => 6)[D.kind])
-lower_D!(d, D) = error("BazingaHIP: D of type $(typeof(D)) is not lowered to the device")
+lower_D!(d, D) = :generic
+
+# ---- generic oracles: host callbacks (BZ_*_CALLBACK) --------------------------------------------
+# Whatever the structured types above do not cover — the closures of demo/rosenbrock.jl:39-80, any user type with
+# the package's protocol (src/Bazinga.jl:11-16) — is handed to the library as @cfunction callbacks.  The host
+# evaluates f / grad f, prox_g, c, J'v and proj_D; the L-BFGS and line-search vector work stays on the device.
+# When one of the four is generic, all four travel as callbacks (the structured types have the protocol anyway).
+struct GenericOracles{F,G,C,DD,T}
+    f::F; g::G; c::C; D::DD
+end
+function _cb_f(u::Ptr{Cvoid}, x::Ptr{T}, dfx::Ptr{T}, n::Int64)::Float64 where {T}
+    o = unsafe_pointer_to_objref(u)
+    Float64(Bazinga.gradient!(unsafe_wrap(Array, dfx, n), o.f, unsafe_wrap(Array, x, n)))
+end
+function _cb_g(u::Ptr{Cvoid}, x::Ptr{T}, gamma::Float64, z::Ptr{T}, n::Int64)::Float64 where {T}
+    o = unsafe_pointer_to_objref(u)
+    Float64(Bazinga.prox!(unsafe_wrap(Array, z, n), o.g, unsafe_wrap(Array, x, n), T(gamma)))
+end
+function _cb_ceval(u::Ptr{Cvoid}, x::Ptr{T}, cx::Ptr{T}, n::Int64, ny::Int64)::Cvoid where {T}
+    o = unsafe_pointer_to_objref(u)
+    Bazinga.eval!(unsafe_wrap(Array, cx, ny), o.c, unsafe_wrap(Array, x, n)); nothing
+end
+function _cb_cjt(u::Ptr{Cvoid}, x::Ptr{T}, v::Ptr{T}, jtv::Ptr{T}, n::Int64, ny::Int64)::Cvoid where {T}
+    o = unsafe_pointer_to_objref(u)
+    Bazinga.jtprod!(unsafe_wrap(Array, jtv, n), o.c, unsafe_wrap(Array, x, n), unsafe_wrap(Array, v, ny)); nothing
+end
+function _cb_D(u::Ptr{Cvoid}, v::Ptr{T}, s::Ptr{T}, ny::Int64)::Cvoid where {T}
+    o = unsafe_pointer_to_objref(u)
+    Bazinga.proj!(unsafe_wrap(Array, s, ny), o.D, unsafe_wrap(Array, v, ny)); nothing
+end
+function lower_generic!(d, f, g, c, D, ::Type{T}) where {T}
+    box = Ref(GenericOracles{typeof(f),typeof(g),typeof(c),typeof(D),T}(f, g, c, D))     # rooted by the Problem
+    d.f_kind = 5; d.g_kind = 8; d.c_kind = 2; d.D_kind = 7
+    d.cb_user = pointer_from_objref(box[])
+    d.cb_f_gradient = @cfunction(_cb_f, Float64, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Int64))
+    d.cb_g_prox = @cfunction(_cb_g, Float64, (Ptr{Cvoid}, Ptr{T}, Float64, Ptr{T}, Int64))
+    d.cb_c_eval = @cfunction(_cb_ceval, Cvoid, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Int64, Int64))
+    d.cb_c_jtprod = @cfunction(_cb_cjt, Cvoid, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Int64, Int64))
+    d.cb_D_proj = @cfunction(_cb_D, Cvoid, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Int64))
+    return box
+end
 
 mutable struct Problem
     h::Ptr{Cvoid}
     keep::Any
     function Problem(f, g, c, D, n, ny, ::Type{T}) where {T}
         d = ProblemDesc(dtype = dtype_code(T), n = n, ny = ny)
-        lower_f!(d, f); lower_g!(d, g); lower_c!(d, c); lower_D!(d, D)
+        tmp = (lower_f!(d, f), lower_g!(d, g), lower_c!(d, c), lower_D!(d, D))      # temporaries the descriptor points into
+        keep = any(t -> t === :generic, tmp) ? lower_generic!(d, f, g, c, D, T) : nothing
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        GC.@preserve f g c D check(ccall((:bz_problem_create, lib), Cint,
+        GC.@preserve f g c D tmp keep check(ccall((:bz_problem_create, lib), Cint,
             (Ptr{Cvoid}, Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), context(), Ref(d), h))
-        p = new(h[], (f, g, c, D))
+        p = new(h[], (f, g, c, D, keep))      # generic oracles: the callback box lives as long as the problem
         finalizer(p -> ccall((:bz_problem_destroy, lib), Cvoid, (Ptr{Cvoid},), p.h), p)
     end
 end
@@ -175,10 +226,12 @@ function PANOCplus(; directions = nothing, maxit = 1000, tol = 1e-8, verbose = f
     compact = !(directions isa LBFGS) || directions.compact === nothing ? 2 : Int(directions.compact)
     PANOCplusHIP(PanocOpts(tol = tol, maxit = min(maxit, typemax(Int64)), freq = min(freq, typemax(Int32)),
                            verbose = verbose, minimum_gamma = minimum_gamma, alpha = alpha, beta = beta,
-                           max_backtracks = max_backtracks, lbfgs_memory = M, lbfgs_compact = compact))
+                           max_backtracks = max_backtracks, lbfgs_memory = M, lbfgs_compact = compact,
+                           affine_refresh = get(kwargs, :affine_refresh, 8)))
 end
 
-const _problems = IdDict{Any,Problem}()
+# one device problem per live AugLagFun; the entry (and, through the finalizer, the device buffers) goes with the functor
+const _problems = WeakKeyDict{Any,Problem}()
 
 "`solver(f = alFun, g = gFun, x0 = x) -> (sol, it)`   (alps.jl:66)"
 function (s::PANOCplusHIP)(; f::Bazinga.AugLagFun, g::Bazinga.NonsmoothCostFun, x0::AbstractVector{T}) where {T}
@@ -214,7 +267,7 @@ function alps(f, g, c, D, x0::AbstractVector{T}, y0::AbstractVector{T}; tol::Rea
                 p.h, Ref(ao), Ref(po), x0, y0, x, y, s, mu, st))
     r = st[]
     return x, y, Int(r.tot_it), Int(r.tot_inner_it), r.elapsed_s, _status[r.status + 1], T(r.inner_tol),
-           T(r.norm_res_prim), s, mu
+           (r.tot_it == 0 ? nothing : T(r.norm_res_prim)), s, mu      # alps.jl:34,115: `nothing` before the first outer iteration
 end
 
 end # module

@@ -33,7 +33,7 @@ FAMILIES = [
     ("diag", "zero", "vc"),
     ("diag", "l1", "cc"),
     ("diag", "nonneg", "eitheror"),
-    ("zero", "l1", "xor"),
+    ("diag", "l1", "xor"),
 ]
 
 

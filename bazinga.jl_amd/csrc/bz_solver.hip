@@ -734,7 +734,7 @@ template <class T> class Solver final : public SolverBase {
     // candidates (CXD_, CZN_, GXN_, GZN_) and the images of every stored pair (AS_, AY_: ny-vectors; GS_, GY_: n).
     bool affine_ok_ = false, aff_track_ = false;
     int aff_refresh_ = 8, aff_count_ = 0;
-    int64_t n_affine_ = 0;
+    int64_t n_affine_ = 0, n_affine_verify_ = 0;
     T* cx_keep_ = nullptr;                   // algrad (dense c): also leave c(point) here
     DBuf<T> CXS_, CZS_, CXD_, CZN_, GXN_, GZN_;
     std::vector<DBuf<T>> AS_, AY_, GS_, GY_;
@@ -1933,6 +1933,7 @@ template <class T> class Solver final : public SolverBase {
         const int rp = rc, rn = (rc + 1) % NRR, zp = zc, zn = 1 - zc;
         int xcur = xd;
         bool have_trial = false, fused_this = false, reset_this = false, sep_trial = false;
+        bool img_trial = false;      // grad L (and f) at the trial point x + d are affine images, not evaluations
         // a backtracked trial point can go through the one-pass kernel too ("trial given" variant) when this
         // iteration's first trial did: what that launch used is kept here
         bool trial_ok = false, trial_nt = false;
@@ -2130,7 +2131,7 @@ template <class T> class Solver final : public SolverBase {
             } else if (aff_track_) {
                 // gradient (and c) at x_d into the candidate buffers, then trade: GX_ = grad L(x_d), GXN_ = grad L(x_prev)
                 if (use_compact && gx_valid && gz_valid && aff_count_ + 1 < aff_refresh_) {
-                    ++aff_count_; ++n_affine_;
+                    ++aff_count_; ++n_affine_; img_trial = true;
                     CompactVecs<T, CM> VA = image_vecs(true), VG = image_vecs(false);
                     mv(2 * VA.m + 3, ny); nm("k_affine_image");
                     launch(C_MISC, k_affine_image<T, CM>, grid_y, VA, CC, (const T*)CXS_.p, (const T*)CZS_.p, CXD_.p, ny);
@@ -2211,6 +2212,19 @@ template <class T> class Solver final : public SolverBase {
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));
             const bool halve = f_z > f_z_upp + tol && gamma >= min_gamma;
+            if (halve && img_trial) {
+                // The step-size test compares f(z) with a model built on f(x) and grad L(x) to within 10 eps: an image
+                // (a linear combination, not an evaluation) is not consistent with f(z) to that level near convergence,
+                // and a value a few ulps low would halve gamma again and again at the same point.  A FAILING test is
+                // therefore never trusted on images: evaluate f and grad L at this x with the two passes over A and
+                // run the trial again (this does not consume one of the max_backtracks trials).
+                img_trial = false; aff_count_ = 0; ++n_affine_verify_;
+                cx_keep_ = CXD_.p;
+                algrad(X_[xcur].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
+                cx_keep_ = nullptr;
+                --k;
+                continue;
+            }
             const T FBE_new = f_z_upp + g_z;
             // not a plain iteration: z of the state this step started from may be needed (z_curr below), and
             // it must be formed with the gamma of that state
@@ -2268,7 +2282,7 @@ template <class T> class Solver final : public SolverBase {
                 have_trial = true; gram_from_trial = true; gx_valid = false; gz_valid = false;
                 n_grad += 2; n_prox += 1;
             } else {
-                if (aff_track_) { cx_keep_ = CXD_.p; aff_count_ = 0; }
+                if (aff_track_) { cx_keep_ = CXD_.p; aff_count_ = 0; img_trial = false; }
                 algrad(X_[xb].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
                 cx_keep_ = nullptr;
             }

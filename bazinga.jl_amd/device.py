@@ -118,6 +118,14 @@ class Problem:
         L.check(L.load().bz_problem_create(self.ctx._h, C.byref(desc), C.byref(h)))
         # structured oracles: the library has copied the data.  Generic oracles: the callback thunks (and the list
         # exceptions raised inside them are parked in) must live as long as the problem
+        # split-layout pairwise D (demo/obstacle.jl:151-168): the device works in the interleaved order
+        from .oracles import PairwiseSet, split_permutation
+        self._perm = self._iperm = None
+        if isinstance(D, PairwiseSet) and D.layout == "split" and desc.f_kind != L.BZ_F_CALLBACK:
+            if slack or self.nx != self.ny:
+                raise ValueError("split-layout pairwise sets: c = Identity, no slack form")
+            self._perm = split_permutation(self.nx)
+            self._iperm = np.argsort(self._perm)
         self.generic = desc.f_kind == L.BZ_F_CALLBACK
         self._keep = keep if self.generic else None
         del keep
@@ -137,7 +145,13 @@ class Problem:
         v = np.ascontiguousarray(a, dtype=self.dtype)
         if v.shape != (n,):
             raise ValueError(f"expected a vector of length {n}, got shape {v.shape}")
+        if self._perm is not None:
+            v = np.ascontiguousarray(v[self._perm])
         return v
+
+    def _out(self, v):
+        """device order -> caller's order (split-layout pairwise sets)"""
+        return v if self._iperm is None else np.ascontiguousarray(v[self._iperm])
 
     def set_multipliers(self, mu, y):
         mu, y = self._in(mu, self.ny), self._in(y, self.ny)
@@ -148,7 +162,7 @@ class Problem:
         out = np.empty(self.n, self.dtype)
         st = L.PanocStats()
         self._call(L.load().bz_panoc_solve(self._h, C.byref(opts), x0.ctypes.data, out.ctypes.data, C.byref(st)))
-        return out, st
+        return self._out(out), st
 
     def panoc_begin(self, opts: L.PanocOpts, x0):
         x0 = self._in(x0, self.n)
@@ -188,7 +202,7 @@ class Problem:
         out = np.empty(self.n, self.dtype)
         st = L.PanocStats()
         self._call(L.load().bz_panoc_finish(self._h, out.ctypes.data, C.byref(st)))
-        return out, st
+        return self._out(out), st
 
     def panoc_stats(self):
         st = L.PanocStats()
@@ -207,7 +221,7 @@ class Problem:
         idx = {"x": 0, "z": 1, "res": 2, "grad_x": 3, "grad_z": 4}[which]
         out = np.empty(self.n, self.dtype)
         self._call(L.load().bz_panoc_vector(self._h, idx, out.ctypes.data))
-        return out
+        return self._out(out)
 
     def alps_solve(self, aopts: L.AlpsOpts, popts: L.PanocOpts, x0, y0):
         x0, y0 = self._in(x0, self.nx), self._in(y0, self.ny)
@@ -217,21 +231,21 @@ class Problem:
         fn = L.load().bz_als_solve if self.slack else L.load().bz_alps_solve
         self._call(fn(self._h, C.byref(aopts), C.byref(popts), x0.ctypes.data, y0.ctypes.data,
                                        x.ctypes.data, y.ctypes.data, s.ctypes.data, mu.ctypes.data, C.byref(st)))
-        return x, y, s, mu, st
+        return self._out(x), self._out(y), self._out(s), self._out(mu), st
 
     def eval_al_gradient(self, x):
         x = self._in(x, self.n)
         g = np.empty(self.n, self.dtype)
         vals = (C.c_double * 3)()
         self._call(L.load().bz_eval_al_gradient(self._h, x.ctypes.data, g.ctypes.data, vals))
-        return g, tuple(vals)
+        return self._out(g), tuple(vals)
 
     def eval_prox(self, x, gamma):
         x = self._in(x, self.n)
         z = np.empty(self.n, self.dtype)
         gz = C.c_double()
         self._call(L.load().bz_eval_prox(self._h, x.ctypes.data, float(gamma), z.ctypes.data, C.byref(gz)))
-        return z, gz.value
+        return self._out(z), gz.value
 
     def eval_lbfgs(self, S, Y, v):
         v = self._in(v, self.n)

@@ -291,15 +291,26 @@ class PairwiseSet(ClosedSetBase):
     (orConstraints.jl:7-17 / 24-36)."""
     KINDS = ("vc", "cc", "eitheror", "xor")
 
-    def __init__(self, kind):
+    def __init__(self, kind, layout="adjacent"):
+        """layout="adjacent": pairs (c(x)[2j], c(x)[2j+1]); layout="split": pairs (c(x)[i], c(x)[i+N]), N = ny/2, the way
+        demo/obstacle.jl:151-168 (SetObstacleRed) lays its complementarity pairs out.  The device kernels work on
+        adjacent pairs (a pair is one 16-byte pack); the split layout is the same problem under the interleaving
+        permutation, which the host binding applies to every vector at the boundary (device.Problem)."""
         if kind not in self.KINDS:
             raise ValueError(f"kind must be one of {self.KINDS}")
+        if layout not in ("adjacent", "split"):
+            raise ValueError("layout must be 'adjacent' or 'split'")
         self.kind = kind
+        self.layout = layout
 
     def proj(self, s, v):
         """the 2-element projections over adjacent pairs (host protocol: only used when another oracle of the
         problem is generic)"""
-        x1, x2 = v[0::2], v[1::2]
+        if self.layout == "split":
+            N = v.shape[0] // 2
+            x1, x2 = v[:N], v[N:]
+        else:
+            x1, x2 = v[0::2], v[1::2]
         z1, z2 = x1.copy(), x2.copy()
         if self.kind == "vc":          # vanishingConstraints.jl:27-46
             a = x1 <= 0
@@ -321,8 +332,11 @@ class PairwiseSet(ClosedSetBase):
             up = x1 > x2
             z1[...] = np.where(same, np.where(up, np.maximum(x1, 0), np.minimum(x1, 0)), x1)
             z2[...] = np.where(same, np.where(up, np.minimum(x2, 0), np.maximum(x2, 0)), x2)
-        s[0::2] = z1
-        s[1::2] = z2
+        if self.layout == "split":
+            s[:N], s[N:] = z1, z2
+        else:
+            s[0::2] = z1
+            s[1::2] = z2
 
 
 def VanishingConstraintPairs():
@@ -342,6 +356,15 @@ def XorPairs():
 
 
 # ------------------------------------------------------------------ lowering
+def split_permutation(n):
+    """perm with x_adjacent = x_split[perm]: position 2j holds element j, position 2j+1 element j + N (N = n/2)"""
+    N = n // 2
+    perm = np.empty(n, np.int64)
+    perm[0::2] = np.arange(N)
+    perm[1::2] = np.arange(N) + N
+    return perm
+
+
 def _vec(a, dtype, n, name):
     v = np.ascontiguousarray(a, dtype=dtype)
     if v.shape != (n,):
@@ -430,8 +453,15 @@ def lower(f, g, c, D, n, ny, dtype, slack=False):
     keep = []
     d.dtype, d.n, d.ny = code, n, ny
     d.slack = 1 if slack else 0
+    # split-layout pairwise set: every per-element parameter vector goes to the device in the interleaved
+    # (adjacent-pair) order; device.Problem permutes the state vectors at the boundary with the same map
+    perm = split_permutation(n) if (isinstance(D, PairwiseSet) and D.layout == "split") else None
+    if perm is not None and not isinstance(f, (Zero, DiagQuadratic)):
+        raise UnsupportedOracle("split-layout pairwise sets are lowered with an element-wise f (Zero, DiagQuadratic)")
 
     def ptr(a):
+        if perm is not None and a.ndim == 1 and a.shape[0] == n:
+            a = np.ascontiguousarray(a[perm])
         keep.append(a)
         return a.ctypes.data
 

@@ -195,11 +195,20 @@ class PairwiseSet:
     _P = {"vc": project_onto_VC_set, "cc": project_onto_CC_set, "eitheror": project_onto_EITHEROR_set,
           "xor": project_onto_XOR_set}
 
-    def __init__(self, kind):
+    def __init__(self, kind, layout="adjacent"):
         self.kind = kind
+        self.layout = layout
         self._proj = self._P[kind]
 
     def proj(self, z, x):
+        if self.layout == "split":
+            # demo/obstacle.jl:151-168 (SetObstacleRed): the pairs are (x[i], x[i + N]), i = 1..N
+            N = x.shape[0] // 2
+            for i in range(N):
+                zz = np.empty(2, x.dtype)
+                self._proj(zz, np.array([x[i], x[i + N]], x.dtype))
+                z[i], z[i + N] = zz[0], zz[1]
+            return None
         for j in range(0, x.shape[0], 2):
             self._proj(z[j:j + 2], x[j:j + 2])
         return None

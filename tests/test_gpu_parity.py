@@ -988,6 +988,40 @@ def test_pairwise_sets_alps(bz, ref, kind, g):
         bz.Problem(dev[0], dev[1], dev[2], bz.PairwiseSet(kind), n - 1, n - 1, np.float64)      # odd ny
 
 
+@pytest.mark.parametrize("kind", ["cc", "vc", "eitheror", "xor"])
+def test_pairwise_sets_split_layout(bz, ref, kind):
+    """SURVEY f-2, demo/obstacle.jl:151-168 (SetObstacleRed): the pairs are (c(x)[i], c(x)[i + N]).  The host binding
+    maps the split layout onto the kernels' adjacent pairs by the interleaving permutation at the boundary: the AL
+    gradient is element-wise bit-exact against the oracle's split-layout projection, iterates and whole ALPS solves
+    follow it."""
+    n = 3000
+    d = bz.synth.l1_quadratic(n)
+    dev = (bz.DiagQuadratic(d["q"], 0.2 * d["b"]), bz.NormL1(0.3), bz.IdentityFunction(), bz.PairwiseSet(kind, layout="split"))
+    orc = (ref.DiagQuadratic(d["q"], 0.2 * d["b"]), ref.NormL1(0.3), ref.IdentityFunction(), ref.PairwiseSet(kind, layout="split"))
+    rng = np.random.default_rng(5)
+    x, mu, y = rng.standard_normal(n), 10.0 ** rng.uniform(-2, 1, n), rng.standard_normal(n)
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(mu, y)
+    g_dev, vals = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x)
+    g_ref = np.empty(n)
+    lx = al.gradient(g_ref, x)
+    assert np.array_equal(g_dev, g_ref) and abs(vals[0] - lx) <= 1e-13 * max(1.0, abs(lx))
+    prob.close()
+    prob, st, rows = run_traces(bz, ref, dev, orc, n, np.full(n, 0.1), 0.3 * rng.standard_normal(n), np.zeros(n), 25)
+    for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
+        assert ex <= iter_tol(sens) and ez <= iter_tol(sens), (k, ex, ez, sens)
+    assert sum(r[7] for r in rows) >= 15          # ... through the fused one-pass kernels
+    prob.close()
+    a = bz.alps(*dev, np.zeros(n), np.zeros(n))
+    o = ref.alps(*orc, np.zeros(n), np.zeros(n))
+    assert a[5] == o[5] and a[2] == o[2] and abs(a[3] - o[3]) <= max(2, 0.05 * o[3])
+    assert rel(a[0], o[0]) <= 1e-8 and rel(a[8], o[8]) <= 1e-8          # x and s = proj_D(c(x) + mu y) in the caller's layout
+    z = np.empty(n)
+    orc[3].proj(z, a[0])
+    assert np.max(np.abs(z - a[0])) <= 1e-5
+
+
 @pytest.mark.parametrize("M", [1, 3, 5])
 def test_compact_lbfgs_float32_and_short_memory(bz, ref, M):
     """The compact form with T = Float32 (coefficients are formed in double on the host and applied in

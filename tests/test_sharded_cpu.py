@@ -56,7 +56,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, compact=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -70,7 +70,8 @@ def _worker(rank, world, port, n, q):
     R.set_reducer(red)
     orc = (R.DiagQuadratic(d["q"], d["b"]), R.NormL1(d["lam"]), R.IdentityFunction(),
            R.ClosedSet(R.IndBox(d["lo"], d["hi"])))
-    out = R.alps(*orc, np.zeros(hi - lo), np.zeros(hi - lo))
+    sub = lambda **kw: R.PANOCplus(directions=R.LBFGS(5, compact=compact), **kw)
+    out = R.alps(*orc, np.zeros(hi - lo), np.zeros(hi - lo), subsolver=sub)
     R.set_reducer(None)
     q.put((rank, lo, hi, out[0], out[1], out[2], out[3], out[5], float(out[7]), red.calls))
     dist.barrier()
@@ -78,14 +79,19 @@ def _worker(rank, world, port, n, q):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_equals_unsharded_world2():
+@pytest.mark.parametrize("compact", [False, True])
+def test_sharded_equals_unsharded_world2(compact):
+    """both evaluations of the L-BFGS operator: the two-loop recursion (2M + 1 sequential exchanges per iteration on
+    the GPUs) and the compact representation, whose Gram products, p and w are all partial sums of the same pass —
+    on the GPUs ONE pack of 32 scalars per iteration (k_fused_compact -> k_exchange_collect); here every scalar of
+    that pack goes through the same gather-and-fold-in-rank-order rule."""
     import bazinga_jl_amd as bz
     from oracle import bazinga_ref as R
     n, world = 1000, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, compact)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
@@ -94,7 +100,8 @@ def test_sharded_equals_unsharded_world2():
         assert p.exitcode == 0
     d = bz.synth.l1_quadratic(n)
     ref = R.alps(R.DiagQuadratic(d["q"], d["b"]), R.NormL1(d["lam"]), R.IdentityFunction(),
-                 R.ClosedSet(R.IndBox(d["lo"], d["hi"])), np.zeros(n), np.zeros(n))
+                 R.ClosedSet(R.IndBox(d["lo"], d["hi"])), np.zeros(n), np.zeros(n),
+                 subsolver=lambda **kw: R.PANOCplus(directions=R.LBFGS(5, compact=compact), **kw))
     # identical control flow on every rank and vs the unsharded run
     assert res[0][5:8] == res[1][5:8] == (ref[2], ref[3], ref[5])
     assert res[0][8] == res[1][8]                      # bit-identical primal residual on both ranks

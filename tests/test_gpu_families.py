@@ -74,7 +74,9 @@ def make_family(bz, ref, n, fam, dtype=np.float64):
             DD = m.PairwiseSet(D)
         out.append((ff, gg, m.IdentityFunction(), DD))
     mu = np.full(n, 0.1, dtype)
-    y = rng.standard_normal(n).astype(dtype)
+    # (f = Zero: multipliers large enough that c(x) + mu*y leaves D — otherwise the subproblem is min g(x), solved at 0
+    # in two iterations, and there is nothing to compare)
+    y = ((30.0 if f == "zero" else 1.0) * rng.standard_normal(n)).astype(dtype)
     x0 = (0.3 * rng.standard_normal(n)).astype(dtype)
     return out[0], out[1], mu, y, x0
 

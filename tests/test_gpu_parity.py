@@ -1167,7 +1167,9 @@ def test_dual_safeguard_clamp_on_the_device(bz, ref):
     o = ref.alps(*orc, np.zeros(n), y0.copy(), maxit=1, subsolver=rsub)
     assert a[2] == o[2] == 1 and a[3] == o[3] == 1 and a[5] == o[5]
     assert np.all(np.isfinite(a[1])) and np.max(np.abs(a[1])) <= 1.0001e20
-    assert np.max(np.abs(a[1])) >= 0.9e20                              # the clamp was reached
+    # ... and the clamp was what made them so: the oracle WITHOUT the safeguard ends elsewhere
+    o_raw = ref.alps(*orc, np.zeros(n), y0.copy(), maxit=1, subsolver=rsub, dual_safeguard=lambda y, cx=None: None)
+    assert np.max(np.abs(o_raw[1] - o[1])) >= 1e19
     assert np.max(np.abs(a[1] - o[1])) <= 1e-12 * np.max(np.abs(o[1]))
     assert np.max(np.abs(a[0] - o[0])) <= 1e-12 * max(1.0, np.max(np.abs(o[0])))
     assert np.array_equal(y0[::7], np.full_like(y0[::7], 3e20))          # y0 never mutated

@@ -10,7 +10,7 @@ from .oracles import (CallbackError, ClosedSet, DenseAffine, DiagQuadratic, Free
                       LeastSquares, NormL0Box, NormLpPowerBox, NormLpPowerNonneg, Quadratic,
                       NormL1, NormL1Box, NormL1Nonneg, Stencil5ptQuadratic, UnsupportedOracle, Zero, ZeroSet,
                       PairwiseSet, VanishingConstraintPairs, ComplementarityPairs, EitherOrPairs, XorPairs)
-from .solvers import (LBFGS, NoAcceleration, AugLagFun, AugLagFunSlack, AugLagUpdate, NonsmoothCostFun, NonsmoothCostFunSlack,
+from .solvers import (LBFGS, NoAcceleration, AndersonAcceleration, Broyden, AugLagFun, AugLagFunSlack, AugLagUpdate, NonsmoothCostFun, NonsmoothCostFunSlack,
                       PANOCplus, alps, als,
                       default_dual_safeguard, default_penalty_parameter, default_subsolver)
 

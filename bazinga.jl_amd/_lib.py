@@ -66,7 +66,11 @@ class PanocOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("maxit", C.c_int64), ("freq", C.c_int32), ("verbose", C.c_int32),
                 ("minimum_gamma", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("max_backtracks", C.c_int32), ("lbfgs_memory", C.c_int32), ("fuse", C.c_int32),
-                ("persist", C.c_int32), ("lbfgs_compact", C.c_int32), ("affine_refresh", C.c_int32)]
+                ("persist", C.c_int32), ("lbfgs_compact", C.c_int32), ("affine_refresh", C.c_int32),
+                ("directions", C.c_int32), ("reserved", C.c_int32), ("broyden_theta_bar", C.c_double)]
+
+
+BZ_DIR_LBFGS, BZ_DIR_ANDERSON, BZ_DIR_BROYDEN = 0, 1, 2
 
 
 class PanocStats(C.Structure):

@@ -2898,6 +2898,30 @@ k_fvalue_elem(const T* __restrict__ x, ElemParams<T> P, int64_t n, double* __res
 }
 
 // ---------------------------------------------------------------------------
+// Broyden() directions (ProximalAlgorithms; the modified Broyden update of the PANOC papers, Themelis & Patrinos,
+// "SuperMann", IEEE TAC 2019, §VI-A): a dense n-by-n operator H, row-major; the tiny-n demos only
+// ---------------------------------------------------------------------------
+// H = I
+template <class T>
+__global__ void __launch_bounds__(BLOCK) k_set_identity(T* __restrict__ H, int64_t n) {
+    const int64_t tot = n * n;
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < tot; k += (int64_t)gridDim.x * BLOCK)
+        H[k] = (k / n == k % n) ? T(1) : T(0);
+}
+// H += ((s - Hy) * inv_denom) (x) sH        (rank-one update, element (i, j): u_i * sH_j)
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+k_rank1_update(T* __restrict__ H, const T* __restrict__ s, const T* __restrict__ Hy, const T* __restrict__ sH,
+               T inv_denom, int64_t n) {
+    const int64_t tot = n * n;
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < tot; k += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = k / n, j = k - i * n;
+        const T u = (s[i] - Hy[i]) * inv_denom;
+        H[k] = H[k] + u * sH[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // scalar plumbing
 // ---------------------------------------------------------------------------
 // one host-given number as a reduction slot with a single partial (so that it can travel through an exchange)

@@ -826,6 +826,89 @@ template <class T> class Solver final : public SolverBase {
     int spare = 0;
     T ys_[MAX_MEM + 1];
     T H = T(1);
+    // `directions` other than L-BFGS (bz_panoc_opts.directions)
+    int dir_kind_ = BZ_DIR_LBFGS;
+    T broyden_theta_bar_ = T(0.2);
+    DBuf<T> HB_, BHy_, BsH_;                 // Broyden: the dense operator (n x n, row-major), H y, H's
+    int b_rpc_ = 1, b_nch_ = 1;
+    // Broyden: D_ = H res (the caller forms x_d = x - D_ through the returned tail)
+    TailArgs<T> broyden_dir() {
+        gemv_rows(HB_.p, n, RES_[rc].p, (const T*)nullptr, D_.p);
+        TailArgs<T> t;
+        std::memset(&t, 0, sizeof(t));
+        t.alphas = alphas_.p;
+        t.in = D_.p; t.v = nullptr; t.sgn = T(-1); t.mode = 2; t.apply_H = 0; t.H = T(1);
+        t.src = ScalarSrc{parts_.p, 0, 1}; t.ys = T(1);
+        return t;
+    }
+    void broyden_reset() {
+        launch(C_MISC, k_set_identity<T>, (int)std::min<int64_t>(PSTRIDE, (n * n + BLOCK - 1) / BLOCK), HB_.p, n);
+    }
+    // update!(H, s, y) — the pair sits in S_[spare], Y_[spare]:
+    //   Hy = H y ; sH = s'H ; delta = <Hy, s> / <s, s> ; theta = 1 if |delta| >= theta_bar else
+    //   (1 - sgn(delta) theta_bar) / (1 - delta), sgn(0) = 1 ; H += (s - Hy) / <s, (1/theta - 1) s + Hy> * sH
+    void broyden_update() {
+        const T* sv = S_[spare].p;
+        const T* yv = Y_[spare].p;
+        gemv_rows(HB_.p, n, yv, (const T*)nullptr, BHy_.p);
+        gemv_cols(HB_.p, n, sv, b_rpc_, b_nch_);
+        {
+            ElemParams<T> Pz = P;
+            Pz.f_kind = BZ_F_ZERO;
+            launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, b_nch_, npad, sv, Pz, BsH_.p, n, parts_.p, (int)SL_SCRATCH);
+        }
+        launch(C_MISC, k_dot<T>, grid, (const T*)BHy_.p, sv, T(1), n, parts_.p, (int)SL_AUX);
+        launch(C_MISC, k_dot<T>, grid, sv, sv, T(1), n, parts_.p, (int)SL_AUX + 1);
+        slot_n[SL_AUX] = slot_n[SL_AUX + 1] = grid;
+        gather(SL_AUX, 2, 0u);
+        auto v = collect({SL_AUX, SL_AUX + 1}, 0u);
+        const T hys = T(v[0]), ss = T(v[1]);
+        if (!(ss > T(0))) return;
+        const T delta = hys / ss;
+        T theta = T(1);
+        if (std::abs(delta) < broyden_theta_bar_) {
+            const T sg = delta >= T(0) ? T(1) : T(-1);
+            theta = (T(1) - sg * broyden_theta_bar_) / (T(1) - delta);
+        }
+        const T denom = (T(1) / theta - T(1)) * ss + hys;
+        if (denom == T(0) || denom != denom) return;
+        launch(C_MISC, k_rank1_update<T>, (int)std::min<int64_t>(PSTRIDE, (n * n + BLOCK - 1) / BLOCK), HB_.p, sv,
+               (const T*)BHy_.p, (const T*)BsH_.p, T(1) / denom, n);
+    }
+    // Anderson: a = (Y'Y)^-1 Y'v by elimination with complete pivoting on the Gram matrix (pivots below 1e-14 of the
+    // largest are treated as a rank deficiency: their coefficient is zero)
+    void anderson_coefficients(int m, const double* w, double* a) const {
+        double A[CM * CM], b[CM];
+        int perm[CM];
+        for (int i = 0; i < m; ++i) { b[i] = w[i]; perm[i] = i; for (int j = 0; j < m; ++j) A[i * CM + j] = Gyy[i * CM + j]; }
+        double amax = 0.0;
+        for (int i = 0; i < m; ++i) amax = std::max(amax, std::abs(A[i * CM + i]));
+        int rank = 0;
+        for (int k = 0; k < m; ++k) {
+            int pi = k, pj = k;
+            double best = 0.0;
+            for (int i = k; i < m; ++i)
+                for (int j = k; j < m; ++j)
+                    if (std::abs(A[i * CM + j]) > best) { best = std::abs(A[i * CM + j]); pi = i; pj = j; }
+            if (!(best > 1e-14 * amax)) break;
+            if (pi != k) { for (int j = 0; j < m; ++j) std::swap(A[k * CM + j], A[pi * CM + j]); std::swap(b[k], b[pi]); }
+            if (pj != k) { for (int i = 0; i < m; ++i) std::swap(A[i * CM + k], A[i * CM + pj]); std::swap(perm[k], perm[pj]); }
+            for (int i = k + 1; i < m; ++i) {
+                const double f = A[i * CM + k] / A[k * CM + k];
+                for (int j = k; j < m; ++j) A[i * CM + j] -= f * A[k * CM + j];
+                b[i] -= f * b[k];
+            }
+            rank = k + 1;
+        }
+        double z[CM] = {0};
+        for (int k = rank - 1; k >= 0; --k) {
+            double acc = b[k];
+            for (int j = k + 1; j < rank; ++j) acc -= A[k * CM + j] * z[j];
+            z[k] = acc / A[k * CM + k];
+        }
+        for (int i = 0; i < m; ++i) a[i] = 0.0;
+        for (int k = 0; k < rank; ++k) a[perm[k]] = z[k];
+    }
     // compact form: Gram products of the stored pairs in logical order (oldest first), CM x CM
     bool compact_ok = false;
     int gm = 0;
@@ -1468,6 +1551,7 @@ template <class T> class Solver final : public SolverBase {
         H = T(1);
     }
     void lbfgs_reset() {                 // reset!(H): currmem = curridx = 0, H = 1
+        if (dir_kind_ == BZ_DIR_BROYDEN) broyden_reset();
         gm = 0; pw_valid = false;
         for (int s : order) freeslots.push_back(s);
         order.clear();
@@ -1548,6 +1632,14 @@ template <class T> class Solver final : public SolverBase {
         CompactCoef<CM> C;
         std::memset(&C, 0, sizeof(C));
         C.H0 = (double)H;
+        if (dir_kind_ == BZ_DIR_ANDERSON) {
+            // d = v + (S - Y) a , a = (Y'Y)^-1 Y'v : the compact kernels' linear combination with u1 = a, H0 u2 = -a
+            double a[CM] = {0};
+            anderson_coefficients(m, hw_, a);
+            C.H0 = 1.0;
+            for (int i = 0; i < CM; ++i) { C.u1[i] = i < m ? a[i] : 0.0; C.u2h[i] = i < m ? -a[i] : 0.0; }
+            return C;
+        }
         double M1[CM * CM], M2[CM * CM];
         compact_matrices(C.H0, M1, M2);
         // same loops as LBFGSCompactOperator.__call__ (rows/columns beyond m are zero)
@@ -1574,7 +1666,7 @@ template <class T> class Solver final : public SolverBase {
         ys_[spare] = ys;
         if ((int)order.size() > M) { spare = order.back(); order.pop_back(); }
         else { spare = freeslots.back(); freeslots.pop_back(); }
-        H = ys / yty;
+        H = dir_kind_ == BZ_DIR_ANDERSON ? T(1) : ys / yty;
     }
 
     // d = H(-res) up to the last axpy, which the caller fuses with what follows
@@ -1712,8 +1804,25 @@ template <class T> class Solver final : public SolverBase {
             throw Error(BZ_ERR_ARG, "lbfgs_memory must be in 0..16 (0 = NoAcceleration)");
         if (o.max_backtracks < 1) throw Error(BZ_ERR_ARG, "max_backtracks must be >= 1");
         M = o.lbfgs_memory;
+        if (o.directions != BZ_DIR_LBFGS && o.directions != BZ_DIR_ANDERSON && o.directions != BZ_DIR_BROYDEN)
+            throw Error(BZ_ERR_ARG, "unknown `directions`");
+        dir_kind_ = o.directions;
+        if (dir_kind_ == BZ_DIR_ANDERSON && (M < 1 || M > CM))
+            throw Error(BZ_ERR_ARG, "AndersonAcceleration(n): 1 <= n <= 5");
+        if (dir_kind_ == BZ_DIR_BROYDEN) {
+            if (n > 4096) throw Error(BZ_ERR_UNSUPPORTED, "Broyden() keeps a dense n-by-n operator: n <= 4096");
+            if (ctx->nranks > 1) throw Error(BZ_ERR_UNSUPPORTED, "Broyden() is not sharded");
+            M = 0;                                   // no pair history: the operator is the matrix
+            broyden_theta_bar_ = (T)o.broyden_theta_bar;
+            if (!HB_.p) {
+                HB_.alloc((size_t)n * n); BHy_.alloc(npad); BsH_.alloc(npad);
+                plan_chunks(n, b_rpc_, b_nch_);
+                if (GT_.n < (size_t)b_nch_ * npad) GT_.alloc((size_t)b_nch_ * npad);
+            }
+        }
         alloc_history();
         lbfgs_reset_all();
+        if (dir_kind_ == BZ_DIR_BROYDEN) broyden_reset();
         if (o.lbfgs_compact < 0 || o.lbfgs_compact > 2) throw Error(BZ_ERR_ARG, "lbfgs_compact must be 0, 1 or 2 (auto)");
         if (o.lbfgs_compact == 1 && M > CM) throw Error(BZ_ERR_ARG, "lbfgs_compact supports lbfgs_memory <= 5");
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
@@ -1728,9 +1837,9 @@ template <class T> class Solver final : public SolverBase {
         aff_refresh_ = o.affine_refresh;
         static const int aff_env = std::getenv("BZ_AFFINE") ? std::atoi(std::getenv("BZ_AFFINE")) : -1;
         if (aff_env >= 0) aff_refresh_ = aff_env;
-        aff_track_ = affine_ok_ && aff_refresh_ > 0 && o.lbfgs_compact != 0 && M >= 1 && M <= CM;
+        aff_track_ = affine_ok_ && aff_refresh_ > 0 && o.lbfgs_compact != 0 && M >= 1 && M <= CM && dir_kind_ == BZ_DIR_LBFGS;
         aff_count_ = 0; n_affine_ = 0;
-        compact_ok = M >= 1 && (o.lbfgs_compact == 1 ||
+        compact_ok = M >= 1 && (o.lbfgs_compact == 1 || dir_kind_ == BZ_DIR_ANDERSON ||
                                 (o.lbfgs_compact == 2 && (fused_ok || stencil_fast_ || aff_track_) && M <= CM));
         {
             // persistent two-loop: d must fit the register files (<= 40 packs per thread, one 512-thread
@@ -1919,6 +2028,7 @@ template <class T> class Solver final : public SolverBase {
         CompactCoef<CM> CC;
         TailArgs<T> tail;
         if (use_compact) { CV = compact_vecs(); CC = compact_prepare(CV); std::memset(&tail, 0, sizeof(tail)); }
+        else if (dir_kind_ == BZ_DIR_BROYDEN) { if (!res_valid) ensure_z(); tail = broyden_dir(); }
         else tail = use_persist ? two_loop_persist() : two_loop();
         double gsy[CM] = {0}, gyy[CM] = {0};
         double tp[CM] = {0}, tw[CM] = {0}, tpn = 0.0, twn = 0.0;      // next p, w as measured by the fused trial
@@ -2308,7 +2418,9 @@ template <class T> class Solver final : public SolverBase {
             for (int i = 0; i < CM; ++i) { hp_[i] = 0.0; hw_[i] = 0.0; }
             p_new_ = sep_p; w_new_ = sep_w;
         }
-        if (ys > T(0)) {
+        if (dir_kind_ == BZ_DIR_BROYDEN) {
+            broyden_update();                    // (no curvature test: every pair updates the operator)
+        } else if (ys > T(0) || dir_kind_ == BZ_DIR_ANDERSON) {
             if (compact_ok && !gram_from_trial && !order.empty()) {
                 // the accepted pair is not the one the fused trial measured: its Gram products with the
                 // stored pairs come from their own pass
@@ -2339,7 +2451,7 @@ template <class T> class Solver final : public SolverBase {
         // (xr_run_: how many of the newest stored pairs are differences of ring neighbours.  The pair of an
         // iteration that halved gamma is one too — y = res_new(gamma/2) - res_prev(gamma), as upstream has it —
         // because every iterate in the ring remembers the gamma of its residual, gring_)
-        xr_run_ = (fused_ok && compact_ok && ys > T(0) && xcur == xd) ? (reset_this ? 1 : xr_run_ + 1) : 0;
+        xr_run_ = (fused_ok && compact_ok && (ys > T(0) || dir_kind_ == BZ_DIR_ANDERSON) && xcur == xd) ? (reset_this ? 1 : xr_run_ + 1) : 0;
         gring_[xcur] = (double)gamma;
         if (xr_run_ == 0) rh_stale_ = false;       // (whatever broke the run has materialised the pairs above)
         stop_norm_ = v[9];

@@ -40,6 +40,27 @@ class NoAcceleration:
     memory = 0
 
 
+class AndersonAcceleration:
+    """ProximalAlgorithms.AndersonAcceleration(n) (demo/rosenbrock.jl:100-101): type-II Anderson acceleration over the
+    last n pairs, d = v + (S - Y) (Y \\ v); every pair is kept (no curvature test).  On the device it shares the
+    compact-form kernels: d = v + sum a_i s_i - sum a_i y_i with a = (Y'Y)^-1 Y'v from the Gram products the passes
+    return anyway."""
+
+    def __init__(self, memory=5):
+        if not 1 <= int(memory) <= 5:
+            raise UnsupportedOracle("AndersonAcceleration(n) is lowered for 1 <= n <= 5")
+        self.memory = int(memory)
+
+
+class Broyden:
+    """ProximalAlgorithms.Broyden(; theta_bar = 0.2) (demo/rosenbrock.jl:98-99): the modified Broyden update of the PANOC
+    papers on a dense n-by-n operator — the tiny-n demos only (n <= 4096 here)."""
+    memory = 0
+
+    def __init__(self, theta_bar=0.2):
+        self.theta_bar = float(theta_bar)
+
+
 # ------------------------------------------------------------------ safeguards
 def default_dual_safeguard(y, cx=None):
     """src/utilities/safeguards.jl:2-10"""
@@ -147,8 +168,8 @@ class PANOCplus:
                  minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, persist=True,
                  affine_refresh=8, ctx=None):
         self.directions = directions if directions is not None else LBFGS(5)
-        if not isinstance(self.directions, (LBFGS, NoAcceleration)):
-            raise UnsupportedOracle("only directions=LBFGS(M) and NoAcceleration() are lowered to the device")
+        if not isinstance(self.directions, (LBFGS, NoAcceleration, AndersonAcceleration, Broyden)):
+            raise UnsupportedOracle("directions must be LBFGS(M), NoAcceleration(), AndersonAcceleration(n) or Broyden()")
         self.maxit, self.tol, self.verbose, self.freq = maxit, tol, verbose, freq
         self.minimum_gamma, self.alpha, self.beta = minimum_gamma, alpha, beta
         self.max_backtracks, self.fuse, self.persist, self.ctx = max_backtracks, fuse, persist, ctx
@@ -166,6 +187,10 @@ class PANOCplus:
         o.max_backtracks, o.lbfgs_memory, o.fuse = int(self.max_backtracks), self.directions.memory, int(bool(self.fuse))
         o.persist = int(bool(self.persist))
         o.affine_refresh = self.affine_refresh
+        if isinstance(self.directions, AndersonAcceleration):
+            o.directions = L.BZ_DIR_ANDERSON
+        elif isinstance(self.directions, Broyden):
+            o.directions, o.broyden_theta_bar = L.BZ_DIR_BROYDEN, self.directions.theta_bar
         cm = getattr(self.directions, "compact", None)
         o.lbfgs_compact = 2 if cm is None else int(bool(cm))
         return o

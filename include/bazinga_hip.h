@@ -239,7 +239,16 @@ typedef struct {
                                 reads A twice instead of four times.  1: every evaluation passes over A (no images
                                 used); 0: no image bookkeeping at all (the reference's dataflow).  Needs the compact
                                 L-BFGS form (lbfgs_compact != 0, lbfgs_memory <= 5).                          */
+    int32_t directions;      /* the `directions` keyword of PANOCplus (demo/rosenbrock.jl:96-103):
+                                BZ_DIR_LBFGS (default): LBFGS(lbfgs_memory), lbfgs_memory = 0: NoAcceleration();
+                                BZ_DIR_ANDERSON: AndersonAcceleration(lbfgs_memory), 1 <= lbfgs_memory <= 5;
+                                BZ_DIR_BROYDEN:  Broyden() — a dense n-by-n operator, n <= 4096                 */
+    int32_t reserved;
+    double  broyden_theta_bar; /* Broyden(theta_bar = 0.2)                                                    */
 } bz_panoc_opts;
+#define BZ_DIR_LBFGS    0
+#define BZ_DIR_ANDERSON 1
+#define BZ_DIR_BROYDEN  2
 
 void bz_panoc_default_opts(bz_panoc_opts* o);
 

@@ -728,6 +728,96 @@ class _NoAccelOperator:
         pass
 
 
+class AndersonAcceleration:
+    """``AndersonAcceleration(n)`` directions (demo/rosenbrock.jl:100-101).  EXTERNAL, UNPINNED, restated from the published
+    method (type-II Anderson acceleration: Walker & Ni, SIAM J. Numer. Anal. 49 (2011); Fang & Saad, Numer. Linear
+    Algebra Appl. 16 (2009)): over the last n pairs (s_i, y_i), every pair kept,
+        H = I + (S - Y) Y^+ ,   d = H v = v + (S - Y) (Y \\ v)
+    which satisfies the multisecant equations H y_i = s_i.  PARITY UNPINNED (no reference output pins it)."""
+
+    def __init__(self, memory=5):
+        self.memory = int(memory)
+
+
+class _AndersonOperator:
+    H = 1.0
+
+    def __init__(self, M, x):
+        self.M = M
+        self.S, self.Y = [], []
+
+    @property
+    def currmem(self):
+        return len(self.S)
+
+    def update(self, s, y):
+        self.S.append(s.copy())
+        self.Y.append(y.copy())
+        if len(self.S) > self.M:
+            self.S.pop(0)
+            self.Y.pop(0)
+        return _dot(s, y)
+
+    def reset(self):
+        self.S, self.Y = [], []
+
+    def mul(self, d, v):
+        d[...] = v
+        if self.S:
+            Ym = np.stack(self.Y, axis=1)
+            Sm = np.stack(self.S, axis=1)
+            a = np.linalg.lstsq(Ym.astype(np.float64), v.astype(np.float64), rcond=None)[0].astype(v.dtype)
+            d += (Sm - Ym) @ a
+        return d
+
+
+class Broyden:
+    """``Broyden(; theta_bar = 0.2)`` directions (demo/rosenbrock.jl:98-99).  EXTERNAL, UNPINNED, restated from the
+    published modified Broyden update of the PANOC / SuperMann papers (Themelis & Patrinos, IEEE TAC 64 (2019), §VI-A):
+        delta = <H y, s> / <s, s> ;  theta = 1 if |delta| >= theta_bar else (1 - sgn(delta) theta_bar) / (1 - delta), sgn(0) = 1
+        H <- H + (s - H y) (s'H) / <s, (1/theta - 1) s + H y>
+    on a dense operator started (and reset) at the identity.  PARITY UNPINNED."""
+
+    def __init__(self, theta_bar=0.2):
+        self.theta_bar = float(theta_bar)
+
+
+class _BroydenOperator:
+    currmem = 0
+
+    def __init__(self, theta_bar, x):
+        self.theta_bar = x.dtype.type(theta_bar)
+        self.n = x.shape[0]
+        self.Hm = np.eye(self.n, dtype=x.dtype)
+        self.H = 1.0
+
+    def mul(self, d, v):
+        d[...] = self.Hm @ v
+        return d
+
+    def reset(self):
+        self.Hm = np.eye(self.n, dtype=self.Hm.dtype)
+
+    def update(self, s, y):
+        T = s.dtype.type
+        Hy = self.Hm @ y
+        sH = s @ self.Hm
+        ss = _dot(s, s)
+        hys = _dot(Hy, s)
+        if not ss > 0:
+            return _dot(s, y)
+        delta = hys / ss
+        theta = T(1)
+        if abs(delta) < self.theta_bar:
+            sg = T(1) if delta >= 0 else T(-1)
+            theta = (T(1) - sg * self.theta_bar) / (T(1) - delta)
+        denom = (T(1) / theta - T(1)) * ss + hys
+        if denom == 0 or denom != denom:
+            return _dot(s, y)
+        self.Hm = self.Hm + np.outer((s - Hy) * (T(1) / denom), sH)
+        return _dot(s, y)
+
+
 class LBFGSOperator:
     """Two-loop L-BFGS operator with ring buffer of M pairs.
     update!: insert iff <s,y> > 0, H = ys/yty of the newest pair.
@@ -1000,6 +1090,8 @@ class PANOCplusIteration:
         st = PANOCplusState(
             x=x, f_x=f_x, grad_f_x=grad_f_x, gamma=gamma, y=y, z=z, g_z=g_z, res=x - z,
             H=(_NoAccelOperator() if isinstance(self.directions, NoAcceleration)
+               else _AndersonOperator(self.directions.memory, x) if isinstance(self.directions, AndersonAcceleration)
+               else _BroydenOperator(self.directions.theta_bar, x) if isinstance(self.directions, Broyden)
                else (LBFGSCompactOperator(self.directions.memory, x) if getattr(self.directions, "compact", False)
                      else LBFGSOperator(self.directions.memory, x))),
             x_prev=np.empty_like(x), res_prev=np.empty_like(x), d=np.empty_like(x),

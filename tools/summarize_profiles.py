@@ -49,13 +49,14 @@ def form_of(kernel):
     m = re.match(r"k_fused_compact<(.*)>$", k)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
-        a += ["false", "0", "0", "false", "0"][len(a) - 4:] if len(a) < 9 else []
+        a += ["false", "0", "0", "0", "35"][len(a) - 4:] if len(a) < 9 else []
         # <T, MM, NT, SPEC, OFF32, XR, UNI, TRIAL, FAM>
-        nt, spec, xr, uni, trial = a[2] == "true", a[3] == "true", a[5], a[6], a[7] == "true"
-        fam = a[8] if len(a) > 8 else "0"
+        nt, spec, xr, uni = a[2] == "true", a[3] == "true", a[5], a[6]
+        trial = {"true": "1", "false": "0"}.get(a[7], a[7])
+        fam = a[8] if len(a) > 8 else "35"
         if xr == "2":
-            s = f"k_fused_compact<XR=2,UNI={uni},NT={int(nt)},TRIAL={int(trial)}"
-            return s + (f",FAM={fam}>" if fam != "0" else ">")
+            s = f"k_fused_compact<XR=2,UNI={uni},NT={int(nt)},TRIAL={trial}"
+            return s + (f",FAM={fam}>" if uni == "-1" else ">")      # (the headline family's own instantiations carry no FAM tag)
         if xr == "1":
             return f"k_fused_compact<XR=1,NT={int(nt)}>"
         return f"k_fused_compact<XR=0,SPEC={int(spec)},NT={int(nt)}>"

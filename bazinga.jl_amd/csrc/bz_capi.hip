@@ -210,7 +210,7 @@ int bz_panoc_steps(bz_problem* p, int64_t k) {
     return guard([&] {
         need(p, "problem"); on_device(p->device);
         if (k < 0) throw bz::Error(BZ_ERR_ARG, "k must be nonnegative");
-        for (int64_t i = 0; i < k; ++i) p->s->step();
+        p->s->steps(k);
     });
 }
 int bz_panoc_finish(bz_problem* p, void* x_out, bz_panoc_stats* st) {

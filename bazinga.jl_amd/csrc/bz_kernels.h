@@ -2031,6 +2031,22 @@ template <class T, int MM> struct CompactVecs {
     const T* Y[MM];
     int m;
 };
+// Gated pre-launch of the one-pass kernel (iterate-history form).  What the next iteration's launch needs — which ring
+// slots hold the iterates, gamma, the grid — is known while the current pass still runs, except the coefficients u1,
+// u2h, H0 (and whether z is stored), which the host computes from the current pass's 32 scalars.  So the next launch is
+// made EARLY, right behind the read-back kernel, with a gate: workgroup 0's first lane polls a record in pinned host
+// memory; when the host has the scalars it writes the coefficients and the launch's sequence number there (or the
+// number with the ABORT bit if the iteration did not end the plain way: the kernel then leaves without touching
+// anything).  Workgroup 0 copies the record to device memory and raises a device flag the other workgroups poll.
+// That trades the launch call + dispatch (~9 us) between two passes for one PCIe poll (~1.5 us).  Every poll is bounded.
+struct GateRec {
+    unsigned long long seq;          // gate_seq: go ; gate_seq | GATE_ABORT: leave
+    double u1[5], u2h[5], H0;
+    unsigned long long z;            // where this launch stores z (0: nowhere)
+};
+constexpr unsigned long long GATE_ABORT = 1ull << 63;
+constexpr unsigned GATE_SPIN_HOST = 150000u, GATE_SPIN_DEV = 400000u;      // ~0.2 s each
+
 template <int MM> struct CompactCoef {
     // coefficients of this application, computed by the host from p = S'v, w = Y'v (v = -res) and the Gram
     // matrices:  u1 = M1 p - H0 M2' w ;  u2h = H0 * (-(M2 p))     (entries beyond m are zero)
@@ -2042,6 +2058,11 @@ template <int MM> struct CompactCoef {
     // res_prev(gamma), as upstream has it); a halving resets the memory, so no younger iterate can differ.
     double gam0;
     int uni_rt, trial_rt;      // the kernel's UNI / TRIAL when those template arguments are -1 (family instantiations)
+    // gated pre-launch (gate_seq != 0): u1, u2h, H0 above are not used, they arrive through the gate
+    unsigned long long gate_seq;
+    const GateRec* gate_host;  // pinned host memory (device address)
+    GateRec* gate_dev;
+    int* gate_timeout;
 };
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
@@ -2401,6 +2422,52 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     compact_coefs<T, MM>(C, u1, u2h);
     T H0 = (T)C.H0;
     T gl = gamma * P.g_lambda;
+    if constexpr (XR == 2) {
+        if (C.gate_seq != 0ull) {
+            static_assert(MM <= 5, "GateRec holds five coefficients of each kind");
+            __shared__ unsigned long long gate_sh;
+            if (threadIdx.x == 0) {
+                unsigned long long sq = 0ull;
+                unsigned spins = 0;
+                if (blockIdx.x == 0) {
+                    for (;;) {
+                        sq = sys_load(&C.gate_host->seq);
+                        if ((sq & ~GATE_ABORT) == C.gate_seq) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > GATE_SPIN_HOST) { sq = C.gate_seq | GATE_ABORT; *C.gate_timeout = 6; break; }
+                    }
+                    if (!(sq & GATE_ABORT)) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            __hip_atomic_store(&C.gate_dev->u1[i], sys_load(&C.gate_host->u1[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&C.gate_dev->u2h[i], sys_load(&C.gate_host->u2h[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __hip_atomic_store(&C.gate_dev->H0, sys_load(&C.gate_host->H0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&C.gate_dev->z, sys_load(&C.gate_host->z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&C.gate_dev->seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    for (;;) {
+                        sq = __hip_atomic_load(&C.gate_dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((sq & ~GATE_ABORT) == C.gate_seq) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > GATE_SPIN_DEV) { sq = C.gate_seq | GATE_ABORT; break; }
+                    }
+                }
+                gate_sh = sq;
+            }
+            __syncthreads();
+            if (gate_sh & GATE_ABORT) return;
+#pragma unroll
+            for (int i = 0; i < MM; ++i) {
+                u1[i] = (T)__hip_atomic_load(&C.gate_dev->u1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u2h[i] = (T)__hip_atomic_load(&C.gate_dev->u2h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            H0 = (T)__hip_atomic_load(&C.gate_dev->H0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            z = (T*)__hip_atomic_load(&C.gate_dev->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (SPEC && !OFF32) {      // keep the per-application coefficients in vector registers: scalar ones are the scarce kind here
 #pragma unroll
         for (int i = 0; i < MM; ++i) { asm volatile("" : "+v"(u1[i])); asm volatile("" : "+v"(u2h[i])); }

@@ -117,6 +117,7 @@ struct SolverBase {
     virtual void set_multipliers(const void* mu, const void* y) = 0;
     virtual void begin(const bz_panoc_opts& o, const void* x0_host) = 0;
     virtual void step() = 0;
+    virtual void steps(int64_t k) = 0;
     virtual bool should_stop() const = 0;
     virtual void finish(void* x_out, bz_panoc_stats* st) = 0;
     virtual void scalars(double* out16) = 0;

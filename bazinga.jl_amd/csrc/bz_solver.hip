@@ -299,6 +299,8 @@ template <class T> class Solver final : public SolverBase {
     }
 
     ~Solver() override {
+        if (gate_pending_) { gate_abort(); (void)hipStreamSynchronize(ctx->stream); }
+        if (gate_host_) (void)hipHostFree(gate_host_);
         for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto& e : ev_pool) (void)hipEventDestroy(e);
         for (int r = 0; r < P2P_MAXRANKS; ++r)
@@ -919,6 +921,115 @@ template <class T> class Solver final : public SolverBase {
     bool pw_valid = false;
     double hp_[CM] = {0}, hw_[CM] = {0};
 
+    // ---- gated pre-launch of the next iteration's one-pass kernel (see GateRec in bz_kernels.h) ----
+    struct GatePlan {                        // everything the launch needs except the coefficients and the z store
+        const T* S[CM];
+        const T* x;
+        T* xd;
+        double gam0, gamma;
+        int uni, gfc, fam, m_now;
+        bool nt, table;
+        bool operator==(const GatePlan& o) const {
+            for (int i = 0; i < CM; ++i) if (S[i] != o.S[i]) return false;
+            return x == o.x && xd == o.xd && gam0 == o.gam0 && gamma == o.gamma && uni == o.uni && gfc == o.gfc &&
+                   fam == o.fam && m_now == o.m_now && nt == o.nt && table == o.table;
+        }
+    };
+    GateRec* gate_host_ = nullptr;           // pinned host memory
+    GateRec* gate_host_dev_ = nullptr;       // ... its device address
+    DBuf<GateRec> gate_dev_;
+    unsigned long long gate_seq_ = 0;
+    bool gate_pending_ = false, more_coming_ = false;
+    int gate_env_ = 1;
+    GatePlan gate_plan_{};
+    double gate_bytes_ = 0.0;
+    int64_t n_gated_ = 0, n_gate_aborts_ = 0;
+    void gate_alloc() {
+        if (gate_host_) return;
+        BZ_HIP(hipHostMalloc((void**)&gate_host_, sizeof(GateRec), hipHostMallocMapped));
+        std::memset(gate_host_, 0, sizeof(GateRec));
+        BZ_HIP(hipHostGetDevicePointer((void**)&gate_host_dev_, gate_host_, 0));
+        gate_dev_.alloc(1);
+    }
+    // the plan of the iterate-history launch at ring position xc_ with m_now stored pairs (false: that form does not apply)
+    bool gate_make_plan(int xc_, int m_now, const double* gring, int xr_run, GatePlan& pl) const {
+        const int fam = fused_family();
+        static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
+        static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
+        static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
+        const bool small = off32_env && (double)vcap * sizeof(T) < 4.0e9;
+        if (!(xr_env_ >= 2 && small && fam >= 0 && xr_run >= m_now)) return false;
+        for (int i = 1; i < m_now; ++i)
+            if (gring[(xc_ - m_now + i + NXR) % NXR] != (double)gamma) return false;
+        std::memset(&pl, 0, sizeof(pl));
+        for (int i = 0; i < CM; ++i) {
+            const int slot = (xc_ - std::max(0, m_now - i) + NXR) % NXR;
+            pl.S[i] = X_[slot].p;
+            if (i == 0) pl.gam0 = gring[slot];
+        }
+        pl.x = X_[xc_].p; pl.xd = X_[(xc_ + 1) % NXR].p;
+        pl.gamma = (double)gamma; pl.uni = uni_; pl.fam = fam; pl.m_now = m_now;
+        pl.gfc = gfc_env_ > 0 ? std::min(grid, gfc_env_ * std::max(1, num_cus)) : std::min(grid, std::max(1, num_cus));
+        const int streams = (m_now + 1) + pstreams(true, true, true) - (uni_ >= 1 ? 1 : 0) - (uni_ >= 2 ? 1 : 0) + 1;
+        pl.nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * streams > 340e6;
+        pl.table = !(spec_env && fam == FAM_HEADLINE) || famrt_env_;
+        return true;
+    }
+    void gate_launch(const GatePlan& pl, CompactCoef<CM> C2, T* zarg, bool trial_unused = false) {
+        CompactVecs<T, CM> XV;
+        XV.m = CM;
+        for (int i = 0; i < CM; ++i) { XV.S[i] = pl.S[i]; XV.Y[i] = nullptr; }
+        C2.gam0 = pl.gam0;
+        const T gam = (T)pl.gamma;
+        if (pl.table) {
+            C2.uni_rt = pl.uni; C2.trial_rt = 0;
+            FusedFn<T> fn = family_kernel<T>(pl.fam, pl.nt);
+            if (!fn) throw Error(BZ_ERR_STATE, "no one-pass kernel instantiation for this oracle family");
+            form_[C_FUSED_IT] = "k_fused_compact<XR=2,UNI=-1,NT=" + std::to_string(pl.nt ? 1 : 0) + ",TRIAL=-1,FAM=" + std::to_string(pl.fam) + ">";
+            launch(C_FUSED_IT, fn, pl.gfc, XV, C2, pl.x, (const T*)nullptr, P, gam, pl.xd, zarg, (T*)nullptr, (T*)nullptr,
+                   (T*)nullptr, n, parts_.p, (int)SL_TRIAL);
+        } else {
+            form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + char('0' + pl.uni) + (pl.nt ? ",NT=1" : ",NT=0") + ",TRIAL=0>";
+#define BZ_LAUNCH_G(NT_, UNI_)                                                                                    \
+    launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, pl.gfc, XV, C2, pl.x, (const T*)nullptr, P, gam, \
+           pl.xd, zarg, (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p, (int)SL_TRIAL)
+            if (pl.nt) { if (pl.uni == 2) BZ_LAUNCH_G(true, 2); else if (pl.uni == 1) BZ_LAUNCH_G(true, 1); else BZ_LAUNCH_G(true, 0); }
+            else { if (pl.uni == 2) BZ_LAUNCH_G(false, 2); else if (pl.uni == 1) BZ_LAUNCH_G(false, 1); else BZ_LAUNCH_G(false, 0); }
+#undef BZ_LAUNCH_G
+        }
+    }
+    // launch the NEXT iteration's pass now, gated on the host record
+    void gate_prelaunch(const GatePlan& pl) {
+        gate_alloc();
+        CompactCoef<CM> C2;
+        std::memset(&C2, 0, sizeof(C2));
+        C2.gate_seq = ++gate_seq_; C2.gate_host = gate_host_dev_; C2.gate_dev = gate_dev_.p; C2.gate_timeout = ptimeout_dev_;
+        const int streams = (pl.m_now + 1) + pstreams(true, true, true) - (pl.uni >= 1 ? 1 : 0) - (pl.uni >= 2 ? 1 : 0) + 1;
+        mv(streams);
+        gate_bytes_ = pending_bytes_;
+        gate_launch(pl, C2, (T*)nullptr);
+        gate_plan_ = pl; gate_pending_ = true;
+    }
+    void gate_release(const CompactCoef<CM>& C, T* zstore) {
+        for (int i = 0; i < CM; ++i) { gate_host_->u1[i] = C.u1[i]; gate_host_->u2h[i] = C.u2h[i]; }
+        gate_host_->H0 = C.H0;
+        gate_host_->z = (unsigned long long)(uintptr_t)zstore;
+        std::atomic_thread_fence(std::memory_order_release);
+        *(volatile unsigned long long*)&gate_host_->seq = gate_seq_;
+        gate_pending_ = false; ++n_gated_;
+        if (zstore) bytes_all_[C_FUSED_IT] += (double)n * sizeof(T);
+    }
+    void gate_abort() {
+        if (!gate_pending_) return;
+        std::atomic_thread_fence(std::memory_order_release);
+        *(volatile unsigned long long*)&gate_host_->seq = gate_seq_ | GATE_ABORT;
+        gate_pending_ = false; ++n_gate_aborts_;
+        bytes_all_[C_FUSED_IT] -= gate_bytes_; launches_all_[C_FUSED_IT] -= 1;      // (it left without moving anything)
+    }
+    bool prof_would_pick(int cat) const {
+        return ((prof_mask >> cat) & 1u) && (prof_count[cat] % prof_period) == 0;
+    }
+
     // profiling
     struct ProfRec { int cat; hipEvent_t a, b; double bytes; };
     unsigned prof_mask = 0, prof_period = 1;
@@ -1241,6 +1352,19 @@ template <class T> class Solver final : public SolverBase {
         }
         return collect_run(a);
     }
+    // launch the read-back of slots [first, first + cnt) without waiting; wait_host(cnt, ticket) later
+    unsigned long long collect_launch_range(int first, int cnt, unsigned maxmask) {
+        CollectArgs a;
+        a.n = cnt; a.maxmask = maxmask;
+        for (int i = 0; i < cnt; ++i) a.src[i] = src(first + i);
+        a.ticket = ++collect_seq;
+        static const int wave_env = std::getenv("BZ_COLLECT_WAVE") ? std::atoi(std::getenv("BZ_COLLECT_WAVE")) : 1;
+        bool unit = wave_env != 0;
+        for (int i = 0; i < a.n; ++i) unit = unit && a.src[i].stride == 1;
+        if (unit) launch_b(C_COLLECT, k_collect_w, a.n, 64, a, host_out_dev_);
+        else launch(C_COLLECT, k_collect, a.n, a, host_out_dev_);
+        return a.ticket;
+    }
     std::vector<double> collect_run(CollectArgs& a) {
         a.ticket = ++collect_seq;
         static const int wave_env = std::getenv("BZ_COLLECT_WAVE") ? std::atoi(std::getenv("BZ_COLLECT_WAVE")) : 1;
@@ -1282,6 +1406,7 @@ template <class T> class Solver final : public SolverBase {
                         : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
                         : code == 4 ? "stencil halo exchange timed out waiting for a neighbour rank"
                         : code == 5 ? "dense-constraint all-reduce timed out waiting for a peer rank"
+                        : code == 6 ? "a pre-launched pass timed out at its gate (the host never released it)"
                                     : "persistent two-loop kernel: p2p phase exchange timed out waiting for a peer rank");
         }
         std::vector<double> out(a.n);
@@ -1838,7 +1963,7 @@ template <class T> class Solver final : public SolverBase {
         static const int aff_env = std::getenv("BZ_AFFINE") ? std::atoi(std::getenv("BZ_AFFINE")) : -1;
         if (aff_env >= 0) aff_refresh_ = aff_env;
         aff_track_ = affine_ok_ && aff_refresh_ > 0 && o.lbfgs_compact != 0 && M >= 1 && M <= CM && dir_kind_ == BZ_DIR_LBFGS;
-        aff_count_ = 0; n_affine_ = 0;
+        aff_count_ = 0; n_affine_ = 0; n_gated_ = 0; n_gate_aborts_ = 0;
         compact_ok = M >= 1 && (o.lbfgs_compact == 1 || dir_kind_ == BZ_DIR_ANDERSON ||
                                 (o.lbfgs_compact == 2 && (fused_ok || stencil_fast_ || aff_track_) && M <= CM));
         {
@@ -1872,6 +1997,8 @@ template <class T> class Solver final : public SolverBase {
         fused_begin_env_ = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
+        gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 1;
+        gate_abort();
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
         const T eps = std::numeric_limits<T>::epsilon();
@@ -1964,10 +2091,14 @@ template <class T> class Solver final : public SolverBase {
     void run_to_completion() {
         for (;;) {
             const bool stop = should_stop();
+            if (stop) gate_abort();              // (a pass pre-launched for an iteration that will not happen)
             if (opt.verbose && (stop || (opt.freq > 0 && k_ % opt.freq == 0))) display();
             if (stop) break;
+            more_coming_ = k_ + 1 < opt.maxit;   // the solver's own loop: another iteration follows unless this one stops it
             step();
         }
+        more_coming_ = false;
+        gate_abort();
     }
 
     void display() {
@@ -1983,9 +2114,24 @@ template <class T> class Solver final : public SolverBase {
 
     // ---------------------------------------- Base.iterate(iter, state)  (k += 1)
    public:
+    void steps(int64_t k) override {
+        for (int64_t i = 0; i < k; ++i) {
+            more_coming_ = i + 1 < k;            // (the caller asked for all k: the next pass may be launched early)
+            step();
+        }
+        more_coming_ = false;
+    }
     void step() override {
         require_active();
-        if (!persist_ok) { step_impl(); return; }
+        if (!persist_ok) {
+            try {
+                step_impl();
+            } catch (...) {
+                gate_abort();
+                throw;
+            }
+            return;
+        }
         // a grid barrier of the persistent two-loop kernel that cannot complete (its workgroups are not all
         // resident: another stream or process holds CUs) is reported through the next read-back; nothing of the
         // state has been committed by then, so the iteration is simply redone with the kernel chain, and the
@@ -2106,6 +2252,7 @@ template <class T> class Solver final : public SolverBase {
             const int xr2_streams = (m_now + 1) + pstreams(true, true, true) - (uni >= 1 ? 1 : 0) - (uni >= 2 ? 1 : 0) + 1;
             const int nvec = (xr == 2 ? xr2_streams : 2 * CM + 5 + pstreams(true, true, true)) + (zstore ? 1 : 0);
             const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * nvec > 340e6;
+            if (gate_pending_ && xr != 2) gate_abort();
             if (xr == 2) {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
@@ -2115,29 +2262,24 @@ template <class T> class Solver final : public SolverBase {
                     XV.Y[i] = nullptr;
                     if (i == 0) CC.gam0 = gring_[slot];
                 }
-#define BZ_LAUNCH_FC2(NT_, UNI_)                                                                                  \
-    launch(C_FUSED_IT, k_fused_compact<T, CM, NT_, true, true, 2, UNI_>, gfc, XV, CC, (const T*)X_[xp].p,        \
-           (const T*)nullptr, P, gamma, X_[xd].p, zstore, (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p,     \
-           (int)SL_TRIAL)
-                // streams: the m_now + 1 distinct iterates (x among them), the family's parameter vectors (mu / mu*y
-                // unless passed as numbers); x_d (z)
-                mv(xr2_streams + (zstore ? 1 : 0));
                 const bool table = !headline || famrt_env_;
-                if (table) {
-                    // every other element-wise family: its own instantiation (kinds and streams fixed at compile time),
-                    // UNI / TRIAL as run-time arguments
-                    CC.uni_rt = uni; CC.trial_rt = 0;
-                    FusedFn<T> fn = family_kernel<T>(fam, nt);
-                    if (!fn) throw Error(BZ_ERR_STATE, "no one-pass kernel instantiation for this oracle family");
-                    form_[C_FUSED_IT] = "k_fused_compact<XR=2,UNI=-1,NT=" + std::to_string(nt ? 1 : 0) + ",TRIAL=-1,FAM=" + std::to_string(fam) + ">";
-                    launch(C_FUSED_IT, fn, gfc, XV, CC, (const T*)X_[xp].p, (const T*)nullptr, P, gamma, X_[xd].p, zstore,
-                           (T*)nullptr, (T*)nullptr, (T*)nullptr, n, parts_.p, (int)SL_TRIAL);
+                GatePlan cur;
+                std::memset(&cur, 0, sizeof(cur));
+                for (int i = 0; i < CM; ++i) cur.S[i] = XV.S[i];
+                cur.x = X_[xp].p; cur.xd = X_[xd].p; cur.gam0 = CC.gam0; cur.gamma = (double)gamma; cur.uni = uni; cur.gfc = gfc;
+                cur.fam = fam; cur.m_now = m_now; cur.nt = nt; cur.table = table;
+                if (gate_pending_ && cur == gate_plan_) {
+                    // this very launch was made early, behind the previous iteration's read-back: hand it its coefficients
+                    gate_release(CC, zstore);
                 } else {
-                    form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + char('0' + uni) + (nt ? ",NT=1" : ",NT=0") + ",TRIAL=0>";
-                    if (nt) { if (uni == 2) BZ_LAUNCH_FC2(true, 2); else if (uni == 1) BZ_LAUNCH_FC2(true, 1); else BZ_LAUNCH_FC2(true, 0); }
-                    else { if (uni == 2) BZ_LAUNCH_FC2(false, 2); else if (uni == 1) BZ_LAUNCH_FC2(false, 1); else BZ_LAUNCH_FC2(false, 0); }
+                    gate_abort();
+                    // streams: the m_now + 1 distinct iterates (x among them), the family's parameter vectors (mu / mu*y
+                    // unless passed as numbers); x_d (z)
+                    mv(xr2_streams + (zstore ? 1 : 0));
+                    CompactCoef<CM> C2 = CC;
+                    C2.gate_seq = 0ull;
+                    gate_launch(cur, C2, zstore);
                 }
-#undef BZ_LAUNCH_FC2
                 sy_stale_ = true; rh_stale_ = true; res_skipped = true;
                 const int tf_now = trialfuse_env_;
                 trial_ok = tf_now != 0; trial_nt = nt; trial_uni = uni; trial_gfc = gfc; trial_XV = XV; trial_CC = CC;
@@ -2183,6 +2325,19 @@ template <class T> class Solver final : public SolverBase {
                 tail_used = true;
             } else {
                 gather(SL_TRIAL, NFC, 1u << 9);
+                if (xr == 2 && gate_env_) {      // the read-back kernel now, so that the next pass can queue right behind it
+                    tail_ticket = collect_launch_range(SL_TRIAL, NFC, 1u << 9);
+                    tail_used = true;
+                }
+            }
+            if (xr == 2 && gate_env_ && more_coming_ && !opt.verbose && !prof_would_pick(C_FUSED_IT)) {
+                // the NEXT iteration's pass, assuming this one ends the plain way (trial accepted, pair inserted, same
+                // gamma): ring one step on, one more pair
+                double gr[NXR];
+                for (int i = 0; i < NXR; ++i) gr[i] = gring_[i];
+                gr[xd] = (double)gamma;
+                GatePlan nxt;
+                if (gate_make_plan(xd, std::min(m_now + 1, M), gr, xr_run_ + 1, nxt)) gate_prelaunch(nxt);
             }
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
             n_grad += 2; n_prox += 1;
@@ -2340,6 +2495,8 @@ template <class T> class Solver final : public SolverBase {
             // it must be formed with the gamma of that state
             // ... and the classic kernels that finish this iteration need the stored pairs (and the residual of
             // that state) as vectors
+            // a pass pre-launched for the next iteration assumed this trial is accepted and its pair inserted
+            if (gate_pending_ && !(k == 1 && !halve && (FBE_new <= threshold || k >= max_bt) && T(v[7]) > T(0))) gate_abort();
             if (halve) trial_ok = false;
             if (sy_stale_ && !trial_ok && (halve || !(FBE_new <= threshold || k >= max_bt))) materialize_pairs();
             if ((!z_valid || !res_valid) && (halve || !(FBE_new <= threshold || k >= max_bt))) ensure_z();
@@ -2473,6 +2630,8 @@ template <class T> class Solver final : public SolverBase {
         st->status = std::isnan((double)f_x) ? 2 : ((double)stop_norm_ <= opt.tol ? 0 : 1);
         st->persist_fallbacks = (int32_t)n_persist_fallbacks_;
         st->n_affine_images = n_affine_;
+        st->n_gated_launches = n_gated_;
+        st->n_gate_aborts = n_gate_aborts_;
     }
 };
 

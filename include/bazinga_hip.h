@@ -272,6 +272,10 @@ typedef struct {
     int32_t persist_fallbacks;/* times the persistent two-loop kernel's grid barrier timed out (its workgroups
                                  were not co-resident) and the solve went on with the kernel chain (0 or 1)   */
     int64_t n_affine_images;  /* AL gradients formed from stored images instead of two passes over A          */
+    int64_t n_gated_launches; /* iterations whose one-pass kernel was launched EARLY, behind the previous read-back,
+                                 and released through its gate (bz_panoc_steps / bz_panoc_solve / bz_alps_solve:
+                                 wherever the library itself runs the loop); BZ_GATE=0 turns it off                */
+    int64_t n_gate_aborts;    /* ... and early launches recalled because the iteration did not end the plain way   */
 } bz_panoc_stats;
 
 /* Multipliers/penalties of the current subproblem:  AugLagUpdate!(alFun, mu, y)

@@ -40,13 +40,14 @@ Base.@kwdef mutable struct PanocOpts
     minimum_gamma::Float64 = 1e-7; alpha::Float64 = 0.95; beta::Float64 = 0.5
     max_backtracks::Int32 = 20; lbfgs_memory::Int32 = 5; fuse::Int32 = 1; persist::Int32 = 1
     lbfgs_compact::Int32 = 2; affine_refresh::Int32 = 8
+    directions::Int32 = 0; reserved::Int32 = 0; broyden_theta_bar::Float64 = 0.2      # BZ_DIR_LBFGS / _ANDERSON (1) / _BROYDEN (2)
 end
 Base.@kwdef mutable struct PanocStats
     iters::Int64 = 0; f_z::Float64 = 0; g_z::Float64 = 0; al_z::Float64 = 0; gamma::Float64 = 0
     tau::Float64 = 0; stop_norm::Float64 = 0; n_grad::Int64 = 0; n_prox::Int64 = 0
     n_backtracks::Int64 = 0; n_gamma_halvings::Int64 = 0; n_fused_iters::Int64 = 0
     n_lbfgs_skips::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; persist_fallbacks::Int32 = 0
-    n_affine_images::Int64 = 0
+    n_affine_images::Int64 = 0; n_gated_launches::Int64 = 0; n_gate_aborts::Int64 = 0
 end
 
 Base.@kwdef mutable struct AlpsOpts

@@ -1433,3 +1433,41 @@ def test_moved_bytes_accounting_of_the_one_pass_kernel(bz, ref):
         assert p["bytes"] == 10 * 9 * 8 * n and p["timed_bytes"] == p["bytes"]
         assert p["form"].startswith("k_fused_compact<XR=2,UNI=2,NT=") and p["form"].endswith("TRIAL=0>")
     assert 0 < p["timed_bytes"] / (p["timed_ms"] * 1e-3) / 8e12 <= 1.0
+
+
+@pytest.mark.parametrize("fam", ["headline", "l1box"])
+def test_gated_prelaunch_is_bitwise_neutral(bz, ref, fam, monkeypatch):
+    """The next iteration's one-pass kernel launched EARLY behind the read-back and released through its gate
+    (bz_panoc_steps: the library runs the loop) against plain launches: the same bits through tau backtracks, gamma
+    halvings and skipped pairs — the recalled launches leave without touching anything."""
+    n = 400_003
+    d, dev, orc = make_cfg2(bz, ref, n, g="l1" if fam == "headline" else "l1box")
+    rng = np.random.default_rng(21)
+    mu, y, x0 = np.full(n, 0.1), rng.standard_normal(n), 0.05 * rng.standard_normal(n)
+    runs = []
+    for gate in ("0", "1"):
+        monkeypatch.setenv("BZ_GATE", gate)
+        prob = bz.Problem(*dev, n, n, np.float64)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps)).c_opts(), x0)
+        for chunk in (1, 7, 50, 50, 33):
+            prob.panoc_steps(chunk)
+            zmid = prob.panoc_vector("z")                     # between the calls nothing is pending
+        st = prob.panoc_stats()
+        runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), zmid, prob.panoc_scalars(), st))
+        prob.close()
+    a, b = runs
+    for u, v in zip(a[:4], b[:4]):
+        assert np.array_equal(u, v)
+    for key in ("k", "gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "FBE"):
+        assert a[4][key] == b[4][key], key
+    assert a[5].n_gated_launches == 0 and a[5].n_gate_aborts == 0
+    assert b[5].n_gated_launches >= 100 and b[5].n_gated_launches + b[5].n_gate_aborts <= 141 - 5
+    assert (a[5].n_backtracks, a[5].n_gamma_halvings, a[5].n_lbfgs_skips, a[5].n_grad) == \
+        (b[5].n_backtracks, b[5].n_gamma_halvings, b[5].n_lbfgs_skips, b[5].n_grad)
+    # whole solves through the library's own loop: same counts and point with and without the gate
+    outs = []
+    for gate in ("0", "1"):
+        monkeypatch.setenv("BZ_GATE", gate)
+        outs.append(bz.alps(*dev, np.zeros(n), np.zeros(n)))
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3] and np.array_equal(outs[0][0], outs[1][0])

@@ -2040,9 +2040,15 @@ template <class T, int MM> struct CompactVecs {
 // anything).  Workgroup 0 copies the record to device memory and raises a device flag the other workgroups poll.
 // That trades the launch call + dispatch (~9 us) between two passes for one PCIe poll (~1.5 us).  Every poll is bounded.
 struct GateRec {
-    unsigned long long seq;          // gate_seq: go ; gate_seq | GATE_ABORT: leave
-    double u1[5], u2h[5], H0;
-    unsigned long long z;            // where this launch stores z (0: nowhere)
+    // HOST record (pinned, written by the host, polled over PCIe by workgroup 0's first wave): the 13 values travel in
+    // "LL" form like the scalar mailboxes — every 8-byte word carries half a value and the 32-bit tag of the launch it
+    // is meant for, so a word is valid exactly when its tag matches and ONE round of 26 parallel loads fetches
+    // everything (a sequence number followed by the payload would be two PCIe round trips, ~1.5 us each).
+    //   w[2i], w[2i+1]: value i = u1[0..4], u2h[0..4], H0, z (address bits) ; w[31]: tag | 1 = leave without running
+    unsigned long long w[32];
+    // DEVICE copy (written by workgroup 0, read by everybody): seq = gate_seq (go) or gate_seq | GATE_ABORT
+    unsigned long long seq;
+    double val[13];
 };
 constexpr unsigned long long GATE_ABORT = 1ull << 63;
 constexpr unsigned GATE_SPIN_HOST = 150000u, GATE_SPIN_DEV = 400000u;      // ~0.2 s each
@@ -2426,28 +2432,32 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         if (C.gate_seq != 0ull) {
             static_assert(MM <= 5, "GateRec holds five coefficients of each kind");
             __shared__ unsigned long long gate_sh;
-            if (threadIdx.x == 0) {
+            const unsigned long long tag = (unsigned long long)ll_tag(C.gate_seq) << 32;
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
                 unsigned long long sq = 0ull;
                 unsigned spins = 0;
                 if (blockIdx.x == 0) {
+                    unsigned long long word = 0ull;
                     for (;;) {
-                        sq = sys_load(&C.gate_host->seq);
-                        if ((sq & ~GATE_ABORT) == C.gate_seq) break;
+                        if (lane < 32) word = sys_load(&C.gate_host->w[lane]);
+                        const bool mine = lane < 32 && (word >> 32 << 32) == tag;
+                        const unsigned long long ok = __ballot(mine);
+                        if (ok & (1ull << 31)) { sq = C.gate_seq | GATE_ABORT; break; }
+                        if ((ok & 0x3FFFFFFull) == 0x3FFFFFFull) { sq = C.gate_seq; break; }
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > GATE_SPIN_HOST) { sq = C.gate_seq | GATE_ABORT; *C.gate_timeout = 6; break; }
+                        if (++spins > GATE_SPIN_HOST) { sq = C.gate_seq | GATE_ABORT; if (lane == 0) *C.gate_timeout = 6; break; }
                     }
-                    if (!(sq & GATE_ABORT)) {
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) {
-                            __hip_atomic_store(&C.gate_dev->u1[i], sys_load(&C.gate_host->u1[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&C.gate_dev->u2h[i], sys_load(&C.gate_host->u2h[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        __hip_atomic_store(&C.gate_dev->H0, sys_load(&C.gate_host->H0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&C.gate_dev->z, sys_load(&C.gate_host->z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // even lanes 0, 2, .., 24 assemble value lane/2 from their word and the next lane's
+                    const unsigned lo = (unsigned)word, hi = (unsigned)__shfl((unsigned)word, lane + 1, 64);
+                    if (!(sq & GATE_ABORT) && lane < 26 && (lane & 1) == 0) {
+                        const unsigned long long bits = (unsigned long long)lo | ((unsigned long long)hi << 32);
+                        __hip_atomic_store(&C.gate_dev->val[lane >> 1], __longlong_as_double((long long)bits), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&C.gate_dev->seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
+                    if (lane == 0) __hip_atomic_store(&C.gate_dev->seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (lane == 0) {
                     for (;;) {
                         sq = __hip_atomic_load(&C.gate_dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((sq & ~GATE_ABORT) == C.gate_seq) break;
@@ -2455,17 +2465,17 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                         if (++spins > GATE_SPIN_DEV) { sq = C.gate_seq | GATE_ABORT; break; }
                     }
                 }
-                gate_sh = sq;
+                if (lane == 0) gate_sh = sq;
             }
             __syncthreads();
             if (gate_sh & GATE_ABORT) return;
 #pragma unroll
             for (int i = 0; i < MM; ++i) {
-                u1[i] = (T)__hip_atomic_load(&C.gate_dev->u1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u2h[i] = (T)__hip_atomic_load(&C.gate_dev->u2h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u1[i] = (T)__hip_atomic_load(&C.gate_dev->val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u2h[i] = (T)__hip_atomic_load(&C.gate_dev->val[5 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            H0 = (T)__hip_atomic_load(&C.gate_dev->H0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            z = (T*)__hip_atomic_load(&C.gate_dev->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            H0 = (T)__hip_atomic_load(&C.gate_dev->val[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            z = (T*)(uintptr_t)__double_as_longlong(__hip_atomic_load(&C.gate_dev->val[11], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
     }
     if (SPEC && !OFF32) {      // keep the per-application coefficients in vector registers: scalar ones are the scarce kind here

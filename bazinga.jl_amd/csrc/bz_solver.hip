@@ -1011,18 +1011,28 @@ template <class T> class Solver final : public SolverBase {
         gate_plan_ = pl; gate_pending_ = true;
     }
     void gate_release(const CompactCoef<CM>& C, T* zstore) {
-        for (int i = 0; i < CM; ++i) { gate_host_->u1[i] = C.u1[i]; gate_host_->u2h[i] = C.u2h[i]; }
-        gate_host_->H0 = C.H0;
-        gate_host_->z = (unsigned long long)(uintptr_t)zstore;
+        // 12 values (u1, u2h, H0, the z address) as tagged half-words: any order, each word validates itself
+        double vals[13] = {0};
+        for (int i = 0; i < CM; ++i) { vals[i] = C.u1[i]; vals[5 + i] = C.u2h[i]; }
+        vals[10] = C.H0;
+        const unsigned long long zbits = (unsigned long long)(uintptr_t)zstore;
+        std::memcpy(&vals[11], &zbits, sizeof(double));
+        const unsigned long long tag = (unsigned long long)ll_tag(gate_seq_) << 32;
+        volatile unsigned long long* w = gate_host_->w;
+        for (int i = 0; i < 13; ++i) {
+            unsigned long long bits;
+            std::memcpy(&bits, &vals[i], sizeof(bits));
+            w[2 * i] = tag | (bits & 0xFFFFFFFFull);
+            w[2 * i + 1] = tag | (bits >> 32);
+        }
         std::atomic_thread_fence(std::memory_order_release);
-        *(volatile unsigned long long*)&gate_host_->seq = gate_seq_;
         gate_pending_ = false; ++n_gated_;
         if (zstore) bytes_all_[C_FUSED_IT] += (double)n * sizeof(T);
     }
     void gate_abort() {
         if (!gate_pending_) return;
+        *(volatile unsigned long long*)&gate_host_->w[31] = ((unsigned long long)ll_tag(gate_seq_) << 32) | 1ull;
         std::atomic_thread_fence(std::memory_order_release);
-        *(volatile unsigned long long*)&gate_host_->seq = gate_seq_ | GATE_ABORT;
         gate_pending_ = false; ++n_gate_aborts_;
         bytes_all_[C_FUSED_IT] -= gate_bytes_; launches_all_[C_FUSED_IT] -= 1;      // (it left without moving anything)
     }

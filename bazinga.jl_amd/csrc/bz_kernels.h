@@ -2051,7 +2051,7 @@ struct GateRec {
     double val[13];
 };
 constexpr unsigned long long GATE_ABORT = 1ull << 63;
-constexpr unsigned GATE_SPIN_HOST = 150000u, GATE_SPIN_DEV = 400000u;      // ~0.2 s each
+constexpr unsigned GATE_SPIN_HOST = 150000u, GATE_SPIN_DEV = 300000u;      // ~0.2 s each
 
 template <int MM> struct CompactCoef {
     // coefficients of this application, computed by the host from p = S'v, w = Y'v (v = -res) and the Gram
@@ -2461,7 +2461,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                     for (;;) {
                         sq = __hip_atomic_load(&C.gate_dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((sq & ~GATE_ABORT) == C.gate_seq) break;
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(24);      // (~0.7 us: 255 pollers must not load the fabric while a pass streams)
                         if (++spins > GATE_SPIN_DEV) { sq = C.gate_seq | GATE_ABORT; break; }
                     }
                 }
@@ -2469,6 +2469,9 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
             __syncthreads();
             if (gate_sh & GATE_ABORT) return;
+            // this kernel may have been resident while the previous pass (another stream) was still writing what it
+            // is about to read: every wave takes an agent-scope acquire before its first load
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
             for (int i = 0; i < MM; ++i) {
                 u1[i] = (T)__hip_atomic_load(&C.gate_dev->val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

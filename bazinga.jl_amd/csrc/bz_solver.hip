@@ -103,6 +103,7 @@ enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 
 template <class T> class Solver final : public SolverBase {
    public:
     Solver(Ctx* c, const bz_problem_desc& d) : ctx(c), desc(d), n(d.n), ny(d.ny), nx(d.n), slack(d.slack != 0) {
+        cur_ = ctx->stream;
         if (n <= 0 || ny < 0) throw Error(BZ_ERR_ARG, "n must be positive");
         if (d.c_kind == BZ_C_IDENTITY && ny != n)
             throw Error(BZ_ERR_ARG, "c = Identity requires ny == n");
@@ -299,7 +300,9 @@ template <class T> class Solver final : public SolverBase {
     }
 
     ~Solver() override {
-        if (gate_pending_) { gate_abort(); (void)hipStreamSynchronize(ctx->stream); }
+        gate_abort();
+        if (gate_stream_) { (void)hipStreamSynchronize(gate_stream_); (void)hipStreamDestroy(gate_stream_); }
+        (void)hipStreamSynchronize(ctx->stream);
         if (gate_host_) (void)hipHostFree(gate_host_);
         for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto& e : ev_pool) (void)hipEventDestroy(e);
@@ -935,6 +938,11 @@ template <class T> class Solver final : public SolverBase {
                    fam == o.fam && m_now == o.m_now && nt == o.nt && table == o.table;
         }
     };
+    // The early launch goes on the OTHER of two streams, so that it is dispatched (and, registers permitting, resident)
+    // while the current pass still runs instead of queueing behind the read-back kernel; when it is released the
+    // solver's launches move over to that stream (everything on the old one has completed by then: the host has the
+    // read-back's scalars in hand).  Between library calls the solver is always back on the context's stream.
+    hipStream_t cur_ = nullptr, gate_stream_ = nullptr, gate_on_ = nullptr;
     GateRec* gate_host_ = nullptr;           // pinned host memory
     GateRec* gate_host_dev_ = nullptr;       // ... its device address
     DBuf<GateRec> gate_dev_;
@@ -950,6 +958,12 @@ template <class T> class Solver final : public SolverBase {
         std::memset(gate_host_, 0, sizeof(GateRec));
         BZ_HIP(hipHostGetDevicePointer((void**)&gate_host_dev_, gate_host_, 0));
         gate_dev_.alloc(1);
+        BZ_HIP(hipStreamCreateWithFlags(&gate_stream_, hipStreamNonBlocking));
+    }
+    // back on the context's stream, nothing outstanding on the other one (end of every library-run loop)
+    void gate_quiesce() {
+        gate_abort();
+        if (cur_ != ctx->stream) { BZ_HIP(hipStreamSynchronize(cur_)); cur_ = ctx->stream; }
     }
     // the plan of the iterate-history launch at ring position xc_ with m_now stored pairs (false: that form does not apply)
     bool gate_make_plan(int xc_, int m_now, const double* gring, int xr_run, GatePlan& pl) const {
@@ -1007,7 +1021,16 @@ template <class T> class Solver final : public SolverBase {
         const int streams = (pl.m_now + 1) + pstreams(true, true, true) - (pl.uni >= 1 ? 1 : 0) - (pl.uni >= 2 ? 1 : 0) + 1;
         mv(streams);
         gate_bytes_ = pending_bytes_;
-        gate_launch(pl, C2, (T*)nullptr);
+        hipStream_t here = cur_;
+        gate_on_ = (cur_ == ctx->stream) ? gate_stream_ : ctx->stream;
+        cur_ = gate_on_;
+        try {
+            gate_launch(pl, C2, (T*)nullptr);
+        } catch (...) {
+            cur_ = here;
+            throw;
+        }
+        cur_ = here;
         gate_plan_ = pl; gate_pending_ = true;
     }
     void gate_release(const CompactCoef<CM>& C, T* zstore) {
@@ -1026,6 +1049,7 @@ template <class T> class Solver final : public SolverBase {
             w[2 * i + 1] = tag | (bits >> 32);
         }
         std::atomic_thread_fence(std::memory_order_release);
+        cur_ = gate_on_;                         // the rest of this iteration queues behind the released pass
         gate_pending_ = false; ++n_gated_;
         if (zstore) bytes_all_[C_FUSED_IT] += (double)n * sizeof(T);
     }
@@ -1086,6 +1110,7 @@ template <class T> class Solver final : public SolverBase {
     void drain_prof() {
         if (prof_recs.empty()) return;
         BZ_HIP(hipStreamSynchronize(ctx->stream));
+        if (gate_stream_) BZ_HIP(hipStreamSynchronize(gate_stream_));
         for (auto& r : prof_recs) {
             float ms = 0; BZ_HIP(hipEventElapsedTime(&ms, r.a, r.b));
             prof_ms[r.cat] += ms; prof_n[r.cat] += 1; bytes_timed_[r.cat] += r.bytes;
@@ -1104,11 +1129,11 @@ template <class T> class Solver final : public SolverBase {
         if (prof_on) {
             // start/stop events bound to the dispatch itself: kernel time without the launch gap
             r.a = get_event(); r.b = get_event();
-            hipExtLaunchKernelGGL(kernel, dim3(g), dim3(block), 0, ctx->stream, r.a, r.b, 0, args...);
+            hipExtLaunchKernelGGL(kernel, dim3(g), dim3(block), 0, cur_, r.a, r.b, 0, args...);
             prof_recs.push_back(r);
             if (prof_recs.size() > 8192) drain_prof();
         } else {
-            hipLaunchKernelGGL(kernel, dim3(g), dim3(block), 0, ctx->stream, args...);
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(block), 0, cur_, args...);
         }
         BZ_HIP(hipGetLastError());
     }
@@ -1119,10 +1144,10 @@ template <class T> class Solver final : public SolverBase {
         account(cat, prof_on ? &r : nullptr);
         if (prof_on) {
             r.a = get_event(); r.b = get_event();
-            hipExtLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, ctx->stream, r.a, r.b, 0, args...);
+            hipExtLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, cur_, r.a, r.b, 0, args...);
             prof_recs.push_back(r);
         } else {
-            hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, ctx->stream, args...);
+            hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(BLOCK), 0, cur_, args...);
         }
         BZ_HIP(hipGetLastError());
     }
@@ -1319,7 +1344,7 @@ template <class T> class Solver final : public SolverBase {
         launch_b(C_GATHER, k_pack, cnt, 64, (const double*)parts_.p, counts, first, cnt, maxmask, send_.p, ctx->rank,
                  keepmask);
         BZ_NCCL(ncclAllGather(send_.p + first, recv_.p + (size_t)first * ctx->nranks, cnt, ncclDouble,
-                              ctx->comm, ctx->stream));
+                              ctx->comm, cur_));
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
     }
     // p2p transport: k_exchange and the read-back in one launch; returns the ticket wait_host must see
@@ -1400,11 +1425,11 @@ template <class T> class Solver final : public SolverBase {
                 for (int i = 0; i < a.n; ++i)
                     if ((ho[2 * i] & himask) != tag || (ho[2 * i + 1] & himask) != tag) { done = false; break; }
                 if (!done && (spin & 0x3FFu) == 0x3FFu) {
-                    if (hipStreamQuery(ctx->stream) != hipErrorNotReady) break;     // finished or failed
+                    if (!gate_pending_ && hipStreamQuery(cur_) != hipErrorNotReady) break;     // finished or failed
                     if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) break;
                 }
             }
-            if (!done) BZ_HIP(hipStreamSynchronize(ctx->stream));
+            if (!done) { gate_abort(); BZ_HIP(hipStreamSynchronize(cur_)); }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (*ptimeout_) {
@@ -1520,7 +1545,7 @@ template <class T> class Solver final : public SolverBase {
         if (generic_) { algrad_generic(x, grad, slot0); return; }
         if (desc.c_kind == BZ_C_DENSE_AFFINE) {
             eval_c(x);                                                        // cx = A x - b
-            if (cx_keep_) BZ_HIP(hipMemcpyAsync(cx_keep_, CX_.p, ny * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+            if (cx_keep_) BZ_HIP(hipMemcpyAsync(cx_keep_, CX_.p, ny * sizeof(T), hipMemcpyDeviceToDevice, cur_));
             mv(2 + pstreams(false, true, false), ny);
             launch(C_MISC, k_yupd<T>, grid_y, (const T*)CX_.p, P, YU_.p, ny, parts_.p, slot0 + 1);
             slot_n[slot0] = grid; slot_n[slot0 + 1] = grid_y;
@@ -1874,10 +1899,10 @@ template <class T> class Solver final : public SolverBase {
         account(C_PERSIST, prof_on ? &r : nullptr);
         if (prof_on) {
             r.a = get_event(); r.b = get_event();
-            hipExtLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, ctx->stream, r.a, r.b, 0, a);
+            hipExtLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, cur_, r.a, r.b, 0, a);
             prof_recs.push_back(r);
         } else {
-            hipLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, ctx->stream, a);
+            hipLaunchKernelGGL(kernel, dim3(a.nb), dim3(PBLOCK), 0, cur_, a);
         }
         BZ_HIP(hipGetLastError());
     }
@@ -2008,7 +2033,7 @@ template <class T> class Solver final : public SolverBase {
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
         gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 1;
-        gate_abort();
+        gate_quiesce();
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
         const T eps = std::numeric_limits<T>::epsilon();
@@ -2108,7 +2133,7 @@ template <class T> class Solver final : public SolverBase {
             step();
         }
         more_coming_ = false;
-        gate_abort();
+        gate_quiesce();
     }
 
     void display() {
@@ -2130,6 +2155,7 @@ template <class T> class Solver final : public SolverBase {
             step();
         }
         more_coming_ = false;
+        gate_quiesce();
     }
     void step() override {
         require_active();
@@ -2137,9 +2163,10 @@ template <class T> class Solver final : public SolverBase {
             try {
                 step_impl();
             } catch (...) {
-                gate_abort();
+                try { gate_quiesce(); } catch (...) {}
                 throw;
             }
+            if (!more_coming_) gate_quiesce();
             return;
         }
         // a grid barrier of the persistent two-loop kernel that cannot complete (its workgroups are not all

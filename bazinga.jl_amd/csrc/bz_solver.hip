@@ -948,7 +948,7 @@ template <class T> class Solver final : public SolverBase {
     DBuf<GateRec> gate_dev_;
     unsigned long long gate_seq_ = 0;
     bool gate_pending_ = false, more_coming_ = false;
-    int gate_env_ = 1;
+    int gate_env_ = 0;
     GatePlan gate_plan_{};
     double gate_bytes_ = 0.0;
     int64_t n_gated_ = 0, n_gate_aborts_ = 0;
@@ -2032,7 +2032,9 @@ template <class T> class Solver final : public SolverBase {
         fused_begin_env_ = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
-        gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 1;
+        // (off by default: built, bitwise neutral, and measured to gain nothing — the ~10 us between two passes are the
+        // read-back kernel, its PCIe write, the host's turn-around and one PCIe poll either way; NEXT.md)
+        gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 0;
         gate_quiesce();
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));

@@ -859,13 +859,13 @@ template <class T>
 __global__ void __launch_bounds__(BLOCK)
 k_stencil_fb(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, T gamma,
              T* __restrict__ grad, T* __restrict__ z, T* __restrict__ res, int64_t n,
-             double* __restrict__ parts, int slot_f, int slot_g) {
+             double* __restrict__ parts, int slot_f, int slot_g, StencilHalo<T> halo) {
     double accF[2] = {0.0, 0.0}, accG[3] = {0.0, 0.0, 0.0};
     const T gl = gamma * P.g_lambda;
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> xc = ld(x, i0, cnt);
-        Pack<T> pg = stencil_al_pack(x, P, nx, ny, 0, i0, cnt, xc, accF[0], accF[1]);
+        Pack<T> pg = stencil_al_pack(x, P, nx, ny, 0, i0, cnt, xc, accF[0], accF[1], halo);
         ElemLoads<T> L;
         load_params(P, i0, cnt, L, false, false, true);
         Pack<T> pz, pr;
@@ -900,12 +900,12 @@ k_stencil_update(const T* __restrict__ zp, ElemParams<T> P, int64_t nx, int64_t 
                  const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restrict__ res,
                  const T* __restrict__ res_prev, const T* __restrict__ gx, T gamma,
                  T* __restrict__ s_new, T* __restrict__ y_new, T* __restrict__ gz_out, int64_t n,
-                 double* __restrict__ parts, int slot_f, int slot_u) {
+                 double* __restrict__ parts, int slot_f, int slot_u, StencilHalo<T> halo) {
     double accF[2] = {0.0, 0.0}, accU[3] = {0.0, 0.0, 0.0};
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> zc = ld(zp, i0, cnt);
-        Pack<T> pgz = stencil_al_pack(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1]);
+        Pack<T> pgz = stencil_al_pack(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1], halo);
         Pack<T> px = ld(x, i0, cnt), pxp = ld(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ld(res_prev, i0, cnt);
         Pack<T> pgx = ld(gx, i0, cnt), ps, py;
 #pragma unroll
@@ -2321,7 +2321,7 @@ k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T>
                    const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restrict__ res,
                    const T* __restrict__ res_prev, const T* __restrict__ gx, T gamma,
                    T* __restrict__ s_new, T* __restrict__ y_new, int64_t n,
-                   double* __restrict__ parts, int slot0) {
+                   double* __restrict__ parts, int slot0, StencilHalo<T> halo) {
     constexpr int NS = 5 + 4 * MM + 2;
     double accF[2] = {0.0, 0.0}, acc[NS];
 #pragma unroll
@@ -2330,7 +2330,7 @@ k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T>
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;
         Pack<T> zc = ld(zp, i0, cnt);
-        Pack<T> pgz = stencil_al_pack(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1]);
+        Pack<T> pgz = stencil_al_pack(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1], halo);
         Pack<T> px = ld(x, i0, cnt), pxp = ld(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ld(res_prev, i0, cnt);
         Pack<T> pgx = ld(gx, i0, cnt), ps, py, hs[MM], hy[MM];
 #pragma unroll

@@ -2206,8 +2206,11 @@ template <class T> class Solver final : public SolverBase {
         // direction d = H(-res): all but the last axpy
         // (headline family: the one-pass kernel also serves an EMPTY memory — d = H0 (-res), all coefficients zero —
         // so the first iteration of a solve is a 3..5-stream pass too instead of k_fused_sep's 12)
+        // (the stencil fast path also serves a row-sharded grid: the halo rows of x_d and of z travel before the two
+        // passes, and with the compact form the iteration has ONE scalar exchange — the 32 slots of k_stencil_update_c)
+        const bool stencil_fast_now = stencil_fast_ && (!ctx->multi() || (ctx->p2p_on && compact_ok));
         const bool use_compact = compact_ok && (!order.empty() || (fused_ok && fused_family() >= 0) ||
-                                                (stencil_fast_ && !ctx->multi()) || aff_track_);
+                                                stencil_fast_now || aff_track_);
         const bool use_persist = persist_ok && !order.empty() && !use_compact;
         CompactVecs<T, CM> CV;
         CompactCoef<CM> CC;
@@ -2404,15 +2407,17 @@ template <class T> class Solver final : public SolverBase {
                 launch(C_XD, k_axpy_dot<T>, grid, tail, (const T*)nullptr, (const T*)X_[xp].p, X_[xd].p, n,
                        parts_.p, 0);
             }
-            if (stencil_fast_ && !ctx->multi()) {
+            if (stencil_fast_now) {
                 // stencil fast path: {AL gradient at x_d + FB step} and {AL gradient at z + pair + stop norm}
                 // as two passes; same partial sums as the four generic kernels of the first trial
                 for (int sidx = SL_FXD; sidx <= SL_STOP; ++sidx) slot_n[sidx] = grid;
                 mv(2 + pstreams(false, true, true) + 3);        // x_d, b + parameters ; grad, z, res
                 nm("k_stencil_fb");
+                const StencilHalo<T> halo_x = halo_exchange(X_[xd].p);
                 launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
-                       (int)SL_GSUM);
+                       (int)SL_GSUM, halo_x);
+                const StencilHalo<T> halo_z = halo_exchange(Z_[zn].p);
                 if (use_compact) {
                     // ... with the Gram products of the new pair and the next application's p, w in the same pass
                     for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
@@ -2420,7 +2425,13 @@ template <class T> class Solver final : public SolverBase {
                     nm("k_stencil_update_c");
                     launch(C_STENCIL_UPD, k_stencil_update_c<T, CM>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
                            (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
-                           (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
+                           (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL,
+                           halo_z);
+                    if (ctx->p2p_on) {
+                        // exchange + fold over the ranks + read-back of all 32 slots in one launch
+                        tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
+                        tail_used = true;
+                    }
                     gram_from_trial = true;
                 } else {
                 mv(2 + pstreams(false, true, false) + 5 + 2);   // z, b + parameters, x_d, x, res, res_prev, grad ; s, y
@@ -2428,7 +2439,7 @@ template <class T> class Solver final : public SolverBase {
                 launch(C_STENCIL_UPD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
                        (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, (T*)nullptr, n, parts_.p,
-                       (int)SL_FZ, (int)SL_YS);
+                       (int)SL_FZ, (int)SL_YS, halo_z);
                 }
                 have_trial = true; gx_valid = true; gz_valid = false;
                 n_grad += 2; n_prox += 1;

@@ -2307,6 +2307,59 @@ k_pairs_from_iterates(SnapVecs<T, MM> V, int m, ElemParams<T> P, T* __restrict__
     });
 }
 
+// k_update with the compact form's products in the same pass (generic kernel chain: dense c, generic oracles, rejected
+// trials): besides <s,y>, <y,y> and the stop norm, the Gram products of the candidate pair with the stored pairs and
+// the products of all pairs with the new residual — the slot layout of k_fused_compact from slot0 + 7 on — so the chain
+// needs ONE read-back per trial instead of three (k_update, k_gram_pair, k_gram_dots).  Same arithmetic as those
+// kernels (mul_acc), same summation tree on the same grid.
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_update_c(CompactVecs<T, MM> V, const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restrict__ res,
+           const T* __restrict__ res_prev, const T* __restrict__ gx, const T* __restrict__ gz, T gamma,
+           T* __restrict__ s_new, T* __restrict__ y_new, int64_t n, double* __restrict__ parts, int slot0) {
+    constexpr int NS = 5 + 4 * MM + 2;
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    const int m = V.m;
+    bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        Pack<T> px = ld(x, i0, cnt), pxp = ld(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ld(res_prev, i0, cnt);
+        Pack<T> pgx = ld(gx, i0, cnt), pgz = ld(gz, i0, cnt), ps, py, hs[MM], hy[MM];
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+            if (i < m) { hs[i] = ld(V.S[i], i0, cnt); hy[i] = ld(V.Y[i], i0, cnt); }
+#pragma unroll
+        for (int e = 0; e < PackN<T>::N; ++e) {
+            T sv = px.v[e] - pxp.v[e];
+            T yv = pr.v[e] - prp.v[e];
+            ps.v[e] = sv; py.v[e] = yv;
+            T w = pr.v[e] / gamma;
+            w = w - pgx.v[e];
+            w = w + pgz.v[e];
+            if (e < cnt) {
+                acc[0] += (double)(sv * yv);
+                acc[1] += (double)(yv * yv);
+                acc[2] = nanmax(acc[2], (double)(w < T(0) ? -w : w));
+                const T nr = T(-1) * pr.v[e];
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < m) {
+                        acc[3 + i] = mul_acc(hs[i].v[e], yv, acc[3 + i]);
+                        acc[3 + MM + i] = mul_acc(hy[i].v[e], yv, acc[3 + MM + i]);
+                        acc[3 + 2 * MM + i] = mul_acc(hs[i].v[e], nr, acc[3 + 2 * MM + i]);
+                        acc[3 + 3 * MM + i] = mul_acc(hy[i].v[e], nr, acc[3 + 3 * MM + i]);
+                    }
+                acc[3 + 4 * MM] = mul_acc(sv, nr, acc[3 + 4 * MM]);
+                acc[3 + 4 * MM + 1] = mul_acc(yv, nr, acc[3 + 4 * MM + 1]);
+            }
+        }
+        st(s_new, i0, cnt, ps);
+        st(y_new, i0, cnt, py);
+    });
+    block_reduce_store<NS>(acc, 4u, parts, slot0 + 7);
+}
+
 // cfg-3 fast path with the compact L-BFGS representation: k_stencil_update plus, in the same pass, everything the
 // next application of the operator needs — the Gram products of the new pair with the stored pairs and the products
 // of all pairs with the new residual (k_fused_compact's slot layout, so the host reads one block of scalars):

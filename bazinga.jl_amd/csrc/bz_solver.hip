@@ -2475,6 +2475,8 @@ template <class T> class Solver final : public SolverBase {
         const T threshold = FBE_x - sigma * (nr0 * nr0) + tol0;
         std::vector<double> v;
         int nbt = 0;
+        bool gen_gram = false;      // the generic trial just launched carried the compact form's products (k_update_c)
+        int m_gram = m_at_trial;    // ... measured against a memory of this many pairs
         for (int k = 1; k <= max_bt; ++k) {
             if (!have_trial) {
                 if (!gx_valid) { algrad(X_[xcur].p, GX_.p, SL_FXD); gx_valid = true; }
@@ -2485,12 +2487,25 @@ template <class T> class Solver final : public SolverBase {
                 if (aff_track_) cx_keep_ = CZN_.p;
                 algrad(Z_[zn].p, gz_dst, SL_FZ); ++n_grad; gz_valid = true;
                 cx_keep_ = nullptr;
+                if (compact_ok) {
+                    // the pair, the stop norm AND the compact form's products (Gram products of the candidate pair, the
+                    // next application's p, w) in one pass and one read-back — against the memory as it is NOW
+                    const CompactVecs<T, CM> VG = compact_vecs();
+                    for (int kk = 0; kk < 3 + 4 * CM + 2; ++kk) slot_n[SL_YS + kk] = grid;
+                    mv(8 + 2 * VG.m); nm("k_update_c");
+                    launch(C_UPDATE, k_update_c<T, CM>, grid, VG, (const T*)X_[xcur].p, (const T*)X_[xp].p,
+                           (const T*)RES_[rn].p, (const T*)RES_[rp].p, (const T*)GX_.p, (const T*)gz_dst, gamma,
+                           S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL);
+                    gather(SL_YS, 3 + 4 * CM + 2, 4u);
+                    gen_gram = true; m_gram = VG.m; tail_used = false;
+                } else {
                 for (int kk = 0; kk < 3; ++kk) slot_n[SL_YS + kk] = grid;
                 mv(8);
                 launch(C_UPDATE, k_update<T>, grid, (const T*)X_[xcur].p, (const T*)X_[xp].p,
                        (const T*)RES_[rn].p, (const T*)RES_[rp].p, (const T*)GX_.p, (const T*)gz_dst, gamma,
                        S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_YS);
                 gather(SL_YS, 3, 4u);
+                }
                 if (aff_track_) {
                     // images of the candidate pair (s = x - x_prev, y = res - res_prev) under c and grad L
                     mv(6, ny);
@@ -2501,8 +2516,9 @@ template <class T> class Solver final : public SolverBase {
                            (const T*)GZ_.p, GS_[spare].p, GY_[spare].p, n);
                 }
             }
-            if (have_trial && gram_from_trial) {
-                v = tail_used ? wait_host(NFC, tail_ticket) : collect_range(SL_TRIAL, NFC, 1u << 9);
+            if ((have_trial && gram_from_trial) || gen_gram) {
+                v = (have_trial && tail_used) ? wait_host(NFC, tail_ticket) : collect_range(SL_TRIAL, NFC, 1u << 9);
+                gram_from_trial = true; gen_gram = false;
                 for (int i = 0; i < CM; ++i) {
                     gsy[i] = v[10 + i]; gyy[i] = v[10 + CM + i];
                     tp[i] = v[10 + 2 * CM + i]; tw[i] = v[10 + 3 * CM + i];
@@ -2615,9 +2631,9 @@ template <class T> class Solver final : public SolverBase {
         last_ys = ys;
         // p, w for the next application: valid iff the accepted point is the one the fused trial measured
         // and the memory was not reset meanwhile (gram_insert shifts them along with the Gram matrices)
-        pw_valid = compact_ok && gram_from_trial && (int)order.size() == m_at_trial;
+        pw_valid = compact_ok && gram_from_trial && (int)order.size() == m_gram;
         if (pw_valid) {
-            for (int i = 0; i < CM; ++i) { hp_[i] = i < m_at_trial ? tp[i] : 0.0; hw_[i] = i < m_at_trial ? tw[i] : 0.0; }
+            for (int i = 0; i < CM; ++i) { hp_[i] = i < m_gram ? tp[i] : 0.0; hw_[i] = i < m_gram ? tw[i] : 0.0; }
             p_new_ = tpn; w_new_ = twn;
         } else if (compact_ok && sep_trial && fused_this && m_at_trial == 0 && order.empty()) {
             // first iteration of a solve (empty memory): the k_fused_sep pass measured the new pair's p and w

@@ -1022,7 +1022,7 @@ template <class T> class Solver final : public SolverBase {
         mv(streams);
         gate_bytes_ = pending_bytes_;
         hipStream_t here = cur_;
-        gate_on_ = (cur_ == ctx->stream) ? gate_stream_ : ctx->stream;
+        gate_on_ = gate_env_ == 2 ? cur_ : ((cur_ == ctx->stream) ? gate_stream_ : ctx->stream);      // BZ_GATE=2: same stream
         cur_ = gate_on_;
         try {
             gate_launch(pl, C2, (T*)nullptr);

@@ -2069,6 +2069,7 @@ template <int MM> struct CompactCoef {
     const GateRec* gate_host;  // pinned host memory (device address)
     GateRec* gate_dev;
     int* gate_timeout;
+    int gate_other_stream;     // launched on another stream than the pass before it (may be resident while that one runs)
 };
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
@@ -2514,7 +2515,8 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                     for (;;) {
                         sq = __hip_atomic_load(&C.gate_dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((sq & ~GATE_ABORT) == C.gate_seq) break;
-                        __builtin_amdgcn_s_sleep(24);      // (~0.7 us: 255 pollers must not load the fabric while a pass streams)
+                        // (other stream: ~0.7 us between polls — 255 pollers must not load the fabric while a pass streams)
+                        if (C.gate_other_stream) __builtin_amdgcn_s_sleep(24); else __builtin_amdgcn_s_sleep(2);
                         if (++spins > GATE_SPIN_DEV) { sq = C.gate_seq | GATE_ABORT; break; }
                     }
                 }
@@ -2524,7 +2526,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             if (gate_sh & GATE_ABORT) return;
             // this kernel may have been resident while the previous pass (another stream) was still writing what it
             // is about to read: every wave takes an agent-scope acquire before its first load
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (C.gate_other_stream) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
             for (int i = 0; i < MM; ++i) {
                 u1[i] = (T)__hip_atomic_load(&C.gate_dev->val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -948,7 +948,7 @@ template <class T> class Solver final : public SolverBase {
     DBuf<GateRec> gate_dev_;
     unsigned long long gate_seq_ = 0;
     bool gate_pending_ = false, more_coming_ = false;
-    int gate_env_ = 0;
+    int gate_env_ = 1;
     GatePlan gate_plan_{};
     double gate_bytes_ = 0.0;
     int64_t n_gated_ = 0, n_gate_aborts_ = 0;
@@ -1022,7 +1022,8 @@ template <class T> class Solver final : public SolverBase {
         mv(streams);
         gate_bytes_ = pending_bytes_;
         hipStream_t here = cur_;
-        gate_on_ = gate_env_ == 2 ? cur_ : ((cur_ == ctx->stream) ? gate_stream_ : ctx->stream);      // BZ_GATE=2: same stream
+        gate_on_ = gate_env_ != 2 ? cur_ : ((cur_ == ctx->stream) ? gate_stream_ : ctx->stream);
+        C2.gate_other_stream = gate_on_ != cur_ ? 1 : 0;
         cur_ = gate_on_;
         try {
             gate_launch(pl, C2, (T*)nullptr);
@@ -2032,9 +2033,9 @@ template <class T> class Solver final : public SolverBase {
         fused_begin_env_ = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
-        // (off by default: built, bitwise neutral, and measured to gain nothing — the ~10 us between two passes are the
-        // read-back kernel, its PCIe write, the host's turn-around and one PCIe poll either way; NEXT.md)
-        gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 0;
+        // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
+        // stream (resident while the previous pass runs: measured slower, kept for the record)
+        gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 1;
         gate_quiesce();
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));

@@ -7,6 +7,9 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 common="--steps 100 --warmup 20 --no-cpu-baseline --no-extras"
+# (BZ_GATE=0: a pass launched early spends its gate wait inside the kernel, which a kernel trace would count as kernel time;
+# bench.py's own HIP events are taken on the launches that are not gated)
+export BZ_GATE=0
 BZ_BENCH_PERIOD=1 rocprofv3 --kernel-trace --stats -d "$out/stats" -o p --output-format csv -- python3 bench.py $common "$@" > "$out/stats.log" 2>&1; echo "$tag stats rc=$?"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$out/fetch" -o f --output-format csv -- python3 bench.py $common "$@" > "$out/fetch.log" 2>&1; echo "$tag fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$out/write" -o w --output-format csv -- python3 bench.py $common "$@" > "$out/write.log" 2>&1; echo "$tag write rc=$?"

@@ -2036,6 +2036,7 @@ template <class T> class Solver final : public SolverBase {
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
         gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 1;
+        if (gate_env_ && fused_ok) gate_alloc();      // (pinned record, device copy, second stream: not inside an iteration)
         gate_quiesce();
         if (x0_dev != X_[0].p)
             BZ_HIP(hipMemcpyAsync(X_[0].p, x0_dev, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));

@@ -355,9 +355,12 @@ def test_allgather_plumbing_single_rank(bz, ref, variant):
         prob.panoc_begin(opts, np.zeros(n))
         for _ in range(14):
             prob.panoc_step()
+        prob.panoc_steps(26)          # (the library's own loop: with the compact form the next pass is launched early, gated)
         res.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(), prob.panoc_stats()))
         prob.close()
         ctx.close()
+    if "compact" in variant:
+        assert all(r[3].n_gated_launches >= 15 for r in res)      # ... behind the exchange on both transports too
     for other in res[1:]:
         assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1])
         assert res[0][2]["stop_norm"] == other[2]["stop_norm"] and res[0][2]["gamma"] == other[2]["gamma"]

@@ -2125,20 +2125,23 @@ __device__ __forceinline__ void compact_d(int m, T H0, const T (&u1)[MM],
 }
 
 // x_d = x + H(-res) in compact form (generic path: stencil / dense / fuse = 0)
-template <class T, int MM>
+//   FULL: the memory holds MM pairs (compile-time trip counts: the 2 MM + 2 loads issue back to back) ; NT: the history
+//   streams bypass the caches (they are read once per pass and exceed the Infinity Cache at the sizes that matter)
+template <class T, int MM, bool FULL = false, bool NT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_compact_xd(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ res,
              const T* __restrict__ x, T* __restrict__ x_d, int64_t n) {
     T u1[MM], u2h[MM];
     compact_coefs<T, MM>(C, u1, u2h);
     const T H0 = (T)C.H0;
+    const int m = FULL ? MM : V.m;
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> pres = ld(res, i0, cnt), px = ld(x, i0, cnt), ps[MM], py[MM], d, o;
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < V.m) { ps[i] = ld(V.S[i], i0, cnt); py[i] = ld(V.Y[i], i0, cnt); }
-        compact_d<T, MM>(V.m, H0, u1, u2h, pres, ps, py, d);
+            if (i < m) { ps[i] = ldp<T, NT>(V.S[i], i0, cnt); py[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
+        compact_d<T, MM>(m, H0, u1, u2h, pres, ps, py, d);
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) o.v[e] = px.v[e] + d.v[e];
         st(x_d, i0, cnt, o);
@@ -2369,7 +2372,7 @@ k_update_c(CompactVecs<T, MM> V, const T* __restrict__ x, const T* __restrict__ 
 //   then <s_new, -res>, <y_new, -res>
 // (slots slot0 + 0..4 are k_stencil_fb's).  With it the iteration has ONE reduction phase and no persistent
 // two-loop kernel with its 2m-1 grid barriers: x_d (k_compact_xd), k_stencil_fb, this.
-template <class T, int MM>
+template <class T, int MM, bool FULL = false, bool NT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T> P, int64_t nx, int64_t ny,
                    const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restrict__ res,
@@ -2380,7 +2383,7 @@ k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T>
     double accF[2] = {0.0, 0.0}, acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-    const int m = V.m;
+    const int m = FULL ? MM : V.m;
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;
         Pack<T> zc = ld(zp, i0, cnt);
@@ -2389,7 +2392,7 @@ k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T>
         Pack<T> pgx = ld(gx, i0, cnt), ps, py, hs[MM], hy[MM];
 #pragma unroll
         for (int i = 0; i < MM; ++i)
-            if (i < m) { hs[i] = ld(V.S[i], i0, cnt); hy[i] = ld(V.Y[i], i0, cnt); }
+            if (i < m) { hs[i] = ldp<T, NT>(V.S[i], i0, cnt); hy[i] = ldp<T, NT>(V.Y[i], i0, cnt); }
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
             T sv = px.v[e] - pxp.v[e];

@@ -2402,6 +2402,14 @@ template <class T> class Solver final : public SolverBase {
             // x_d = x + d ; gradient at x_d ; state.x = x_d
             if (use_compact) {
                 mv(2 * CV.m + 3); nm("k_compact_xd");
+                // (full memory + a history beyond the Infinity Cache: compile-time trip counts, non-temporal history loads)
+                static const int xdnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
+                const bool hist_nt = xdnt_env && (double)n * sizeof(T) * (2 * CV.m + 3) > 340e6;
+                if (CV.m == CM && hist_nt)
+                    launch(C_XD, k_compact_xd<T, CM, true, true>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p, X_[xd].p, n);
+                else if (CV.m == CM)
+                    launch(C_XD, k_compact_xd<T, CM, true, false>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p, X_[xd].p, n);
+                else
                 launch(C_XD, k_compact_xd<T, CM>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p,
                        X_[xd].p, n);
             } else {
@@ -2425,10 +2433,18 @@ template <class T> class Solver final : public SolverBase {
                     for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
                     mv(2 + pstreams(false, true, false) + 5 + 2 + 2 * CV.m);
                     nm("k_stencil_update_c");
-                    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
-                           (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
-                           (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL,
-                           halo_z);
+#define BZ_LAUNCH_SUC(FULL_, NT_)                                                                                 \
+    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
+           (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p, (const T*)RES_[rp].p, \
+           (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL, halo_z)
+                    {
+                        static const int xdnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
+                        const bool hist_nt = xdnt_env && (double)n * sizeof(T) * (2 * CV.m + 12) > 340e6;
+                        if (CV.m == CM && hist_nt) BZ_LAUNCH_SUC(true, true);
+                        else if (CV.m == CM) BZ_LAUNCH_SUC(true, false);
+                        else BZ_LAUNCH_SUC(false, false);
+                    }
+#undef BZ_LAUNCH_SUC
                     if (ctx->p2p_on) {
                         // exchange + fold over the ranks + read-back of all 32 slots in one launch
                         tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);

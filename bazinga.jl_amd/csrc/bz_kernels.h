@@ -951,15 +951,16 @@ k_gemv_n(const T* __restrict__ A, const T* __restrict__ p, const T* __restrict__
         if (!aligned)
             for (int64_t j = threadIdx.x; j < n; j += BLOCK) a0 += row[j] * p[j];
         for (; c + BLOCK < npk; c += 2 * BLOCK) {
-            Pack<T> ra = *reinterpret_cast<const Pack<T>*>(row + c * N);
-            Pack<T> rb = *reinterpret_cast<const Pack<T>*>(row + (c + BLOCK) * N);
+            // (the matrix is streamed once per product: non-temporal, so that it does not evict p and the partials)
+            Pack<T> ra = ldp<T, true>(row, c * N, N);
+            Pack<T> rb = ldp<T, true>(row, (c + BLOCK) * N, N);
             Pack<T> pa = *reinterpret_cast<const Pack<T>*>(p + c * N);
             Pack<T> pb = *reinterpret_cast<const Pack<T>*>(p + (c + BLOCK) * N);
 #pragma unroll
             for (int e = 0; e < N; ++e) { a0 += ra.v[e] * pa.v[e]; a1 += rb.v[e] * pb.v[e]; }
         }
         for (; c < npk; c += BLOCK) {
-            Pack<T> ra = *reinterpret_cast<const Pack<T>*>(row + c * N);
+            Pack<T> ra = ldp<T, true>(row, c * N, N);
             Pack<T> pa = *reinterpret_cast<const Pack<T>*>(p + c * N);
 #pragma unroll
             for (int e = 0; e < N; ++e) a0 += ra.v[e] * pa.v[e];
@@ -1024,8 +1025,8 @@ k_gemv_t(const T* __restrict__ A, const T* __restrict__ v, T* __restrict__ part,
     const T* col = A + c * N;
     int64_t r = r0;
     for (; r + 1 < r1; r += 2) {
-        Pack<T> ra = *reinterpret_cast<const Pack<T>*>(col + r * n);
-        Pack<T> rb = *reinterpret_cast<const Pack<T>*>(col + (r + 1) * n);
+        Pack<T> ra = ldp<T, true>(col, r * n, N);
+        Pack<T> rb = ldp<T, true>(col, (r + 1) * n, N);
         const T va = v[r], vb = v[r + 1];
 #pragma unroll
         for (int e = 0; e < N; ++e) { a0.v[e] += ra.v[e] * va; a1.v[e] += rb.v[e] * vb; }
@@ -1065,8 +1066,8 @@ k_gemv_t_mfma(const float* __restrict__ A, const float* __restrict__ v, float* _
     bz_f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     int64_t i = r0;
     for (; i + 8 <= r1; i += 8) {                                     // two 4-row steps in flight
-        const Pack<float> ma = *reinterpret_cast<const Pack<float>*>(col + (i + k) * n);
-        const Pack<float> mb = *reinterpret_cast<const Pack<float>*>(col + (i + 4 + k) * n);
+        const Pack<float> ma = ldp<float, true>(col, (i + k) * n, 4);      // (non-temporal: the matrix is streamed once)
+        const Pack<float> mb = ldp<float, true>(col, (i + 4 + k) * n, 4);
         const float va = (c == 0) ? v[i + k] : 0.0f;
         const float vb = (c == 0) ? v[i + 4 + k] : 0.0f;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[0], acc0, 0, 0, 0);
@@ -1081,7 +1082,7 @@ k_gemv_t_mfma(const float* __restrict__ A, const float* __restrict__ v, float* _
     for (; i < r1; i += 4) {                                          // ragged tail: rows beyond r1 feed zeros
         const bool ok = (i + k) < r1;
         Pack<float> ma = splat(0.0f);
-        if (ok) ma = *reinterpret_cast<const Pack<float>*>(col + (i + k) * n);
+        if (ok) ma = ldp<float, true>(col, (i + k) * n, 4);
         const float va = (ok && c == 0) ? v[i + k] : 0.0f;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va, ma.v[1], acc1, 0, 0, 0);
@@ -2070,6 +2071,9 @@ template <int MM> struct CompactCoef {
     GateRec* gate_dev;
     int* gate_timeout;
     int gate_other_stream;     // launched on another stream than the pass before it (may be resident while that one runs)
+    int keepx;                 // experiment (BZ_KEEPX): x_d is stored and x loaded with the default cache policy while every
+                               // other stream stays non-temporal, so that the iterate written by one pass may be served from
+                               // the Infinity Cache to the next
 };
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
@@ -2569,7 +2573,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         if (fk == BZ_F_DIAG_QUADRATIC) { S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo); }
         if (uni < 1) S.mu = ldo<T, NT>(P.mu, bo);
         if (uni < 2) S.muy = ldo<T, NT>(P.muy, bo);
-        S.px = ldo<T, NT>(x, bo);
+        if (NT && C.keepx) S.px = ldo<T, false>(x, bo); else S.px = ldo<T, NT>(x, bo);
         if (trial) S.xt = ldo<T, NT>((const T*)x_d, bo);
 #pragma unroll
         for (int i = 0; i < MM; ++i) S.ps[i] = ldo<T, NT>(V.S[i], bo);
@@ -2740,7 +2744,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         }
         if constexpr (O32) {
-            if (!trial) sto<T, NT>(x_d, bo, pxd);
+            if (!trial) { if (NT && C.keepx) sto<T, false>(x_d, bo, pxd); else sto<T, NT>(x_d, bo, pxd); }
             if (z) sto<T, NT>(z, bo, pz);
             if (XR != 2 || res) sto<T, NT>(res, bo, pr);
             if constexpr (XR == 0) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }

@@ -994,6 +994,8 @@ template <class T> class Solver final : public SolverBase {
         XV.m = CM;
         for (int i = 0; i < CM; ++i) { XV.S[i] = pl.S[i]; XV.Y[i] = nullptr; }
         C2.gam0 = pl.gam0;
+        static const int keepx_env = std::getenv("BZ_KEEPX") ? std::atoi(std::getenv("BZ_KEEPX")) : 0;
+        C2.keepx = keepx_env;
         const T gam = (T)pl.gamma;
         if (pl.table) {
             C2.uni_rt = pl.uni; C2.trial_rt = 0;

@@ -795,7 +795,10 @@ template <class T> struct StencilHalo {
     const T* north;      // ny values: the last row of the previous rank, or null
     const T* south;      // ny values: the first row of the next rank, or null
 };
-template <class T>
+//   NTP: the parameter vectors (b, mu, mu*y, the bounds) with non-temporal loads — at grid sizes beyond the Infinity Cache
+//   they are streamed once per pass and would only evict what the passes of one iteration hand to each other
+//   (x_d, grad L(x_d), z, res)
+template <class T, bool NTP = false>
 __device__ __forceinline__ Pack<T> stencil_al_pack(const T* __restrict__ x, const ElemParams<T>& P, int64_t nx,
                                                    int64_t ny, int f_only, int64_t i0, int cnt,
                                                    const Pack<T>& xc, double& accF, double& accP,
@@ -806,9 +809,9 @@ __device__ __forceinline__ Pack<T> stencil_al_pack(const T* __restrict__ x, cons
     Pack<T> xs = (i + 1 < nx) ? ld(x, i0 + ny, cnt) : (halo.south ? ld(halo.south, j0, cnt) : splat(T(0)));
     const T west = (j0 > 0) ? x[i0 - 1] : T(0);
     const T east = (j0 + N < ny) ? x[i0 + N] : T(0);
-    Pack<T> pb = ld(P.b, i0, cnt);
+    Pack<T> pb = ldp<T, NTP>(P.b, i0, cnt);
     ElemLoads<T> L;
-    if (!f_only) load_params(P, i0, cnt, L, false, true, false);
+    if (!f_only) load_params<T, NTP>(P, i0, cnt, L, false, true, false);
     Pack<T> pg;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
@@ -855,7 +858,7 @@ k_algrad_stencil(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t n
 // (z_i depends only on x_d,i and gradL(x_d)_i).  Same arithmetic and summation order as
 // k_algrad_stencil followed by k_fbstep.  slots: slot_f +0 f terms, +1 t^2/mu ; slot_g +0 g terms,
 // +1 <g,res>, +2 ||res||^2
-template <class T>
+template <class T, bool NTP = false>
 __global__ void __launch_bounds__(BLOCK)
 k_stencil_fb(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, T gamma,
              T* __restrict__ grad, T* __restrict__ z, T* __restrict__ res, int64_t n,
@@ -865,9 +868,9 @@ k_stencil_fb(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, T
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
         Pack<T> xc = ld(x, i0, cnt);
-        Pack<T> pg = stencil_al_pack(x, P, nx, ny, 0, i0, cnt, xc, accF[0], accF[1], halo);
+        Pack<T> pg = stencil_al_pack<T, NTP>(x, P, nx, ny, 0, i0, cnt, xc, accF[0], accF[1], halo);
         ElemLoads<T> L;
-        load_params(P, i0, cnt, L, false, false, true);
+        load_params<T, NTP>(P, i0, cnt, L, false, false, true);
         Pack<T> pz, pr;
 #pragma unroll
         for (int e = 0; e < PackN<T>::N; ++e) {
@@ -2391,8 +2394,8 @@ k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T>
     bz_for_chunks<T>(n, [&](const int64_t i0, const auto cnt_) {
         const int cnt = cnt_;
         Pack<T> zc = ld(zp, i0, cnt);
-        Pack<T> pgz = stencil_al_pack(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1], halo);
-        Pack<T> px = ld(x, i0, cnt), pxp = ld(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ld(res_prev, i0, cnt);
+        Pack<T> pgz = stencil_al_pack<T, NT>(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1], halo);
+        Pack<T> px = ld(x, i0, cnt), pxp = ldp<T, NT>(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ldp<T, NT>(res_prev, i0, cnt);
         Pack<T> pgx = ld(gx, i0, cnt), ps, py, hs[MM], hy[MM];
 #pragma unroll
         for (int i = 0; i < MM; ++i)
@@ -2573,7 +2576,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         if (fk == BZ_F_DIAG_QUADRATIC) { S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo); }
         if (uni < 1) S.mu = ldo<T, NT>(P.mu, bo);
         if (uni < 2) S.muy = ldo<T, NT>(P.muy, bo);
-        if (NT && C.keepx) S.px = ldo<T, false>(x, bo); else S.px = ldo<T, NT>(x, bo);
+        if (NT && (C.keepx & 2)) S.px = ldo<T, false>(x, bo); else S.px = ldo<T, NT>(x, bo);
         if (trial) S.xt = ldo<T, NT>((const T*)x_d, bo);
 #pragma unroll
         for (int i = 0; i < MM; ++i) S.ps[i] = ldo<T, NT>(V.S[i], bo);
@@ -2744,7 +2747,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         }
         if constexpr (O32) {
-            if (!trial) { if (NT && C.keepx) sto<T, false>(x_d, bo, pxd); else sto<T, NT>(x_d, bo, pxd); }
+            if (!trial) { if (NT && (C.keepx & 1)) sto<T, false>(x_d, bo, pxd); else sto<T, NT>(x_d, bo, pxd); }
             if (z) sto<T, NT>(z, bo, pz);
             if (XR != 2 || res) sto<T, NT>(res, bo, pr);
             if constexpr (XR == 0) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }

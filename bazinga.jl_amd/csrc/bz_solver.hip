@@ -2426,6 +2426,12 @@ template <class T> class Solver final : public SolverBase {
                 mv(2 + pstreams(false, true, true) + 3);        // x_d, b + parameters ; grad, z, res
                 nm("k_stencil_fb");
                 const StencilHalo<T> halo_x = halo_exchange(X_[xd].p);
+                static const int fbnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
+                if (fbnt_env && (double)n * sizeof(T) * 12 > 340e6)
+                    launch(C_STENCIL_FB, k_stencil_fb<T, true>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
+                           (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
+                           (int)SL_GSUM, halo_x);
+                else
                 launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                        (int)SL_GSUM, halo_x);

@@ -67,7 +67,8 @@ class PanocOpts(C.Structure):
                 ("minimum_gamma", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("max_backtracks", C.c_int32), ("lbfgs_memory", C.c_int32), ("fuse", C.c_int32),
                 ("persist", C.c_int32), ("lbfgs_compact", C.c_int32), ("affine_refresh", C.c_int32),
-                ("directions", C.c_int32), ("reserved", C.c_int32), ("broyden_theta_bar", C.c_double)]
+                ("directions", C.c_int32), ("reserved", C.c_int32), ("broyden_theta_bar", C.c_double),
+                ("gamma", C.c_double), ("Lf", C.c_double), ("adaptive", C.c_int32), ("reserved2", C.c_int32)]
 
 
 BZ_DIR_LBFGS, BZ_DIR_ANDERSON, BZ_DIR_BROYDEN = 0, 1, 2
@@ -87,7 +88,7 @@ class AlpsOpts(C.Structure):
     _fields_ = [("tol_prim", C.c_double), ("tol_dual", C.c_double), ("inner_tol", C.c_double),
                 ("maxit", C.c_int64), ("theta_penalty", C.c_double), ("kappa_penalty", C.c_double),
                 ("kappa_tol", C.c_double), ("subsolver_maxit", C.c_int64), ("verbose", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("warm_start", C.c_int32)]
 
 
 class AlpsStats(C.Structure):

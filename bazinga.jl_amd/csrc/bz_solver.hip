@@ -504,6 +504,8 @@ template <class T> class Solver final : public SolverBase {
             ++tot_it;
             po2.tol = inner_tol;                                     // alps.jl:64
             po2.verbose = ao.verbose;
+            // opt-in (bz_alps_opts.warm_start bit 0): subsolver(tol, verbose; gamma = gamma_prev, adaptive = true)
+            if ((ao.warm_start & 1) && tot_it > 1 && (double)gamma > 0.0) { po2.gamma = (double)gamma; po2.adaptive = 1; }
             // dual_safeguard(y, cx)  alps.jl:62  +  AugLagUpdate!  alps.jl:65, one pass
             aug_lag_update(true);
             begin_dev(po2, x);                                       // alps.jl:66
@@ -604,6 +606,7 @@ template <class T> class Solver final : public SolverBase {
         while (!can_stop) {
             ++tot_it;
             po2.tol = inner_tol; po2.verbose = ao.verbose;
+            if ((ao.warm_start & 1) && tot_it > 1 && (double)gamma > 0.0) { po2.gamma = (double)gamma; po2.adaptive = 1; }
             aug_lag_update(true);                                    // dual_safeguard + AugLagUpdate!(fSlack, mu, y)
             begin_dev(po2, xs);                                      // sub_solver(f=fSlack, g=gSlack, x0=xSlack)
             run_to_completion();
@@ -817,6 +820,8 @@ template <class T> class Solver final : public SolverBase {
     }
     int xc = 0, rc = 0, zc = 0;
     T alpha = T(0.95), beta = T(0.5), min_gamma = T(1e-7), musqy = T(0);
+    T gamma_given_ = T(0);       // bz_panoc_opts.gamma / alpha / Lf (0: estimate a Lipschitz constant)
+    bool adaptive_ = true;       // upstream's `adaptive`: gamma halvings at the start and inside the line search
     T gamma = T(0), tau = T(0), f_x = T(0), g_z = T(0), dot_gr = T(0), ss_res = T(0);
     T f_z_al = T(0), fraw_last = T(0), last_ys = T(0), fbe_last = T(0);
     double stop_norm_ = 0;
@@ -1989,6 +1994,11 @@ template <class T> class Solver final : public SolverBase {
         if (o.lbfgs_compact < 0 || o.lbfgs_compact > 2) throw Error(BZ_ERR_ARG, "lbfgs_compact must be 0, 1 or 2 (auto)");
         if (o.lbfgs_compact == 1 && M > CM) throw Error(BZ_ERR_ARG, "lbfgs_compact supports lbfgs_memory <= 5");
         alpha = (T)o.alpha; beta = (T)o.beta; min_gamma = (T)o.minimum_gamma;
+        // Lf = nothing, gamma = Lf === nothing ? nothing : alpha / Lf, adaptive = gamma === nothing   (upstream's keywords)
+        if (o.gamma < 0.0 || o.Lf < 0.0 || o.gamma != o.gamma || o.Lf != o.Lf) throw Error(BZ_ERR_ARG, "gamma and Lf must be >= 0 (0 = nothing)");
+        if (o.adaptive < -1 || o.adaptive > 1) throw Error(BZ_ERR_ARG, "adaptive must be -1 (default), 0 or 1");
+        gamma_given_ = o.gamma > 0.0 ? (T)o.gamma : (o.Lf > 0.0 ? alpha / (T)o.Lf : T(0));
+        adaptive_ = o.adaptive < 0 ? !(gamma_given_ > T(0)) : o.adaptive != 0;
         fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
         // auto: the compact representation where it makes the whole iteration one pass (the fused separable
@@ -2058,17 +2068,24 @@ template <class T> class Solver final : public SolverBase {
             if (aff_track_) cx_keep_ = CXS_.p;
             algrad(x, GX_.p, SL_FXD); ++n_grad; gx_valid = true;
             cx_keep_ = nullptr;
-            // gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad_f_x)
-            mv(2);
-            launch(C_MISC, k_add_scalar<T>, grid, (const T*)x, T(1), TMP_.p, n);
-            algrad(TMP_.p, GZ_.p, SL_FZ); ++n_grad;
-            mv(4);
-            launch(C_MISC, k_diff_ss2<T>, grid, (const T*)GZ_.p, (const T*)GX_.p, (const T*)TMP_.p, (const T*)x, n,
-                   parts_.p, (int)SL_AUX);
+            if (!(gamma_given_ > T(0))) {
+                // gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad_f_x)
+                mv(2);
+                launch(C_MISC, k_add_scalar<T>, grid, (const T*)x, T(1), TMP_.p, n);
+                algrad(TMP_.p, GZ_.p, SL_FZ); ++n_grad;
+                mv(4);
+                launch(C_MISC, k_diff_ss2<T>, grid, (const T*)GZ_.p, (const T*)GX_.p, (const T*)TMP_.p, (const T*)x, n,
+                       parts_.p, (int)SL_AUX);
+            }
         }
-        slot_n[SL_AUX] = slot_n[SL_AUX + 1] = grid;
-        gather(SL_AUX, 2, 0u);
-        {
+        if (gamma_given_ > T(0)) {
+            // gamma given (or Lf): no Lipschitz estimate; the one-pass start above computed it for free and it is ignored
+            auto v = collect({SL_FXD, SL_PXD}, 0u);
+            f_x = al_value(v[0], v[1]);
+            gamma = gamma_given_;
+        } else {
+            slot_n[SL_AUX] = slot_n[SL_AUX + 1] = grid;
+            gather(SL_AUX, 2, 0u);
             auto v = collect({SL_FXD, SL_PXD, SL_AUX, SL_AUX + 1}, 0u);
             f_x = al_value(v[0], v[1]);
             const T Lest = std::sqrt(T(v[2])) / std::sqrt(T(v[3]));
@@ -2105,7 +2122,8 @@ template <class T> class Solver final : public SolverBase {
             const T nr = std::sqrt(ss_res);
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));
-            if (f_z > f_z_upp + tol && gamma >= min_gamma) {
+            // (upstream: `if (iter.gamma === nothing || iter.adaptive == true)` backtrack_stepsize!)
+            if (adaptive_ && f_z > f_z_upp + tol && gamma >= min_gamma) {
                 gamma = gamma / T(2); ++n_halv;
                 continue;
             }
@@ -2568,7 +2586,7 @@ template <class T> class Solver final : public SolverBase {
             const T nr = std::sqrt(ss_res);
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));
-            const bool halve = f_z > f_z_upp + tol && gamma >= min_gamma;
+            const bool halve = adaptive_ && f_z > f_z_upp + tol && gamma >= min_gamma;
             if (halve && img_trial) {
                 // The step-size test compares f(z) with a model built on f(x) and grad L(x) to within 10 eps: an image
                 // (a linear combination, not an evaluation) is not consistent with f(z) to that level near convergence,

@@ -166,7 +166,7 @@ class PANOCplus:
 
     def __init__(self, *, directions=None, maxit=1000, tol=1e-8, verbose=False, freq=10,
                  minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, persist=True,
-                 affine_refresh=8, ctx=None):
+                 affine_refresh=8, ctx=None, Lf=None, gamma=None, adaptive=None):
         self.directions = directions if directions is not None else LBFGS(5)
         if not isinstance(self.directions, (LBFGS, NoAcceleration, AndersonAcceleration, Broyden)):
             raise UnsupportedOracle("directions must be LBFGS(M), NoAcceleration(), AndersonAcceleration(n) or Broyden()")
@@ -176,6 +176,13 @@ class PANOCplus:
         # affine images (bz_panoc_opts.affine_refresh): dense affine c with D = ZeroSet / FreeSet — 0 off, k >= 1: a
         # pass-over-A evaluation of the trial point's gradient every k-th iteration, images in between
         self.affine_refresh = int(affine_refresh)
+        # upstream's step-size keywords: Lf = nothing, gamma = Lf === nothing ? nothing : alpha / Lf,
+        # adaptive = gamma === nothing
+        self.Lf = Lf
+        self.gamma = gamma if gamma is not None else (None if Lf is None else alpha / Lf)
+        self.adaptive = (self.gamma is None) if adaptive is None else bool(adaptive)
+        if self.gamma is not None and not self.gamma > 0:
+            raise ValueError("gamma must be positive")
         self.stats = None
 
     def c_opts(self) -> L.PanocOpts:
@@ -187,6 +194,9 @@ class PANOCplus:
         o.max_backtracks, o.lbfgs_memory, o.fuse = int(self.max_backtracks), self.directions.memory, int(bool(self.fuse))
         o.persist = int(bool(self.persist))
         o.affine_refresh = self.affine_refresh
+        o.gamma = 0.0 if self.gamma is None else float(self.gamma)
+        o.Lf = 0.0 if self.Lf is None else float(self.Lf)
+        o.adaptive = int(self.adaptive)
         if isinstance(self.directions, AndersonAcceleration):
             o.directions = L.BZ_DIR_ANDERSON
         elif isinstance(self.directions, Broyden):
@@ -227,7 +237,7 @@ def als(f, g, c, D, x0, y0, **kw):
 def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol=None, maxit=100,
          theta_penalty=0.8, kappa_penalty=0.5, kappa_tol=0.1, verbose=False,
          dual_safeguard=default_dual_safeguard, subsolver=default_subsolver,
-         subsolver_maxit=1_000_000_000, resident=None, ctx=None, problem=None, _slack=False):
+         subsolver_maxit=1_000_000_000, resident=None, ctx=None, problem=None, _slack=False, warm_start=False):
     """Bazinga.alps (src/algorithms/alps.jl:7-117): same keywords and defaults, same 10-tuple
     ``(x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu)``
     (status is the Symbol's name as a string).  x0 / y0 are never mutated.
@@ -238,7 +248,11 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     alps.jl does and enters the device at the `subsolver` seam.
 
     problem: an already created device Problem for (f, g, c, D) to run the resident loop on — what a sharded
-    Stencil5ptQuadratic needs, whose halo regions must be connected between the ranks first."""
+    Stencil5ptQuadratic needs, whose halo regions must be connected between the ranks first.
+
+    warm_start (NOT a keyword of the reference; False = alps.jl:64 as written): from the second subproblem on the
+    subsolver is built as ``subsolver(tol=…, verbose=…, gamma=γ_prev, adaptive=True)`` with the step size the previous
+    subproblem ended with — no Lipschitz estimate (one AL gradient less per subproblem: two passes over a dense A)."""
     x0 = np.asarray(x0)
     y0 = np.asarray(y0)
     T = x0.dtype.type
@@ -262,6 +276,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         ao.tol_prim, ao.tol_dual, ao.inner_tol = float(tol_prim), float(tol_dual), float(inner_tol)
         ao.maxit, ao.theta_penalty, ao.kappa_penalty = int(maxit), float(theta_penalty), float(kappa_penalty)
         ao.kappa_tol, ao.subsolver_maxit, ao.verbose = float(kappa_tol), int(subsolver_maxit), int(bool(verbose))
+        ao.warm_start = int(bool(warm_start))
         x, y, s, mu, st = prob.alps_solve(ao, sub.c_opts(), x0, y0)
         if problem is None:
             prob.close()
@@ -292,6 +307,8 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
     norm_res_prim = None
     norm_res_prim_old = None
     if _slack:
+        if warm_start:
+            raise UnsupportedOracle("warm_start with the host outer loop of als: use resident=True")
         return _als_host_loop(f, g, c, D, x, y, cx, s, mu, gFun, objx, tol_prim, tol_dual, inner_tol, maxit,
                               theta_penalty, kappa_penalty, kappa_tol, verbose, dual_safeguard, subsolver,
                               subsolver_maxit, start_time)
@@ -305,12 +322,17 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         print(f"[ Info: initial penalty parameters μ ∈ [{mu.min()}, {mu.max()}]")
         print(f"[ Info: initial inner tolerance {inner_tol}")
     can_stop = solved or tired or broken
+    gamma_prev = None
     while not can_stop:
         tot_it += 1
         dual_safeguard(y, cx)                                   # :62
-        sub_solver = subsolver(tol=inner_tol, verbose=verbose)  # :64
+        if warm_start and gamma_prev is not None:               # (opt-in deviation from :64)
+            sub_solver = subsolver(tol=inner_tol, verbose=verbose, gamma=gamma_prev, adaptive=True)
+        else:
+            sub_solver = subsolver(tol=inner_tol, verbose=verbose)  # :64
         AugLagUpdate(alFun, mu, y)                              # :65
         sub_sol, sub_it = sub_solver(f=alFun, g=gFun, x0=x)     # :66
+        gamma_prev = getattr(gFun, "gamma", None)
         x[...] = sub_sol
         objx = alFun.fx + gFun.gz                               # :68
         tot_inner_it += sub_it

@@ -249,10 +249,25 @@ def whole_alps_rates(bz, oracles, n, ctx):
             L.check(L.load().bz_alps_solve(prob._h, C.byref(ao), C.byref(po), bufs[0], bufs[1], bufs[2], bufs[3], bufs[4],
                                            bufs[5], C.byref(st2)))
             dt2 = time.perf_counter() - t0
+        # the same with bz_alps_opts.warm_start (an opt-in deviation from alps.jl:64): every subproblem
+        # after the first starts at the step size the previous one ended with
+        aw = L.AlpsOpts()
+        C.memmove(C.byref(aw), C.byref(ao), C.sizeof(ao))
+        aw.warm_start = 1
+        st3 = L.AlpsStats()
+        for rep_i in range(2):
+            t0 = time.perf_counter()
+            L.check(L.load().bz_alps_solve(prob._h, C.byref(aw), C.byref(po), bufs[0], bufs[1], bufs[2], bufs[3], bufs[4],
+                                           bufs[5], C.byref(st3)))
+            dt3 = time.perf_counter() - t0
         for p in bufs:
             hip.hipFree(p)
         out["device_pointers"] = {"ms": round(1e3 * dt2, 3), "outer": int(st2.tot_it), "inner": int(st2.tot_inner_it),
                                   "value": round(st2.tot_inner_it / dt2, 2), "unit": "inner iterations/s"}
+        out["device_pointers_warm_start"] = {"ms": round(1e3 * dt3, 3), "outer": int(st3.tot_it), "inner": int(st3.tot_inner_it),
+                                             "value": round(st3.tot_inner_it / dt3, 2), "unit": "inner iterations/s",
+                                             "status": int(st3.status),
+                                             "note": "opt-in: gamma carried across subproblems (not the reference's alps.jl:64)"}
         out["pcie_share_of_host_call"] = round(max(0.0, dt - dt2) / dt, 4)
     except Exception as e:      # noqa: BLE001
         out["device_pointers"] = {"value": None, "note": repr(e)[:200]}

@@ -245,6 +245,14 @@ typedef struct {
                                 BZ_DIR_BROYDEN:  Broyden() — a dense n-by-n operator, n <= 4096                 */
     int32_t reserved;
     double  broyden_theta_bar; /* Broyden(theta_bar = 0.2)                                                    */
+    /* the step-size keywords of PANOCplus (upstream `Lf = nothing`, `gamma = Lf === nothing ? nothing :
+     * alpha / Lf`, `adaptive = gamma === nothing`); what a warm-started outer loop passes down (bz_alps_opts.warm_start) */
+    double  gamma;           /* 0 (default) = nothing: gamma = alpha / lower_bound_smoothness_constant(f, I, x, grad) ;
+                                > 0: the initial step size, no Lipschitz estimate (one AL gradient less per solve)    */
+    double  Lf;              /* 0 (default) = nothing; > 0 and gamma == 0: gamma = alpha / Lf                         */
+    int32_t adaptive;        /* -1 (default): true exactly when neither gamma nor Lf is given; 1: backtrack_stepsize!
+                                (gamma halvings) at the start and inside every line-search trial; 0: gamma is kept   */
+    int32_t reserved2;
 } bz_panoc_opts;
 #define BZ_DIR_LBFGS    0
 #define BZ_DIR_ANDERSON 1
@@ -314,7 +322,12 @@ typedef struct {
     double  theta_penalty, kappa_penalty, kappa_tol;
     int64_t subsolver_maxit;   /* only the threshold of alps.jl:70                    */
     int32_t verbose;
-    int32_t reserved;
+    int32_t warm_start;        /* SURVEY 8(f-1), an OPT-IN deviation from alps.jl:64 (0, the default, is the reference):
+                                  bit 0: from the second subproblem on the subsolver starts at the step size gamma the
+                                  previous subproblem ended with (`subsolver(tol, verbose; gamma = gamma_prev, adaptive =
+                                  true)`) instead of estimating a Lipschitz constant again: one AL gradient (two passes
+                                  over a dense A) and the first halvings less per subproblem.  gamma never grows inside
+                                  PANOCplus, so after the penalties shrink it is at most too small, never unsafe.      */
 } bz_alps_opts;
 
 void bz_alps_default_opts(bz_alps_opts* o, int32_t dtype);

@@ -41,6 +41,7 @@ Base.@kwdef mutable struct PanocOpts
     max_backtracks::Int32 = 20; lbfgs_memory::Int32 = 5; fuse::Int32 = 1; persist::Int32 = 1
     lbfgs_compact::Int32 = 2; affine_refresh::Int32 = 8
     directions::Int32 = 0; reserved::Int32 = 0; broyden_theta_bar::Float64 = 0.2      # BZ_DIR_LBFGS / _ANDERSON (1) / _BROYDEN (2)
+    gamma::Float64 = 0; Lf::Float64 = 0; adaptive::Int32 = -1; reserved2::Int32 = 0  # 0 = nothing; adaptive -1 = (gamma === nothing)
 end
 Base.@kwdef mutable struct PanocStats
     iters::Int64 = 0; f_z::Float64 = 0; g_z::Float64 = 0; al_z::Float64 = 0; gamma::Float64 = 0
@@ -53,7 +54,7 @@ end
 Base.@kwdef mutable struct AlpsOpts
     tol_prim::Float64 = 1e-6; tol_dual::Float64 = 1e-6; inner_tol::Float64 = cbrt(1e-6)
     maxit::Int64 = 100; theta_penalty::Float64 = 0.8; kappa_penalty::Float64 = 0.5; kappa_tol::Float64 = 0.1
-    subsolver_maxit::Int64 = 1_000_000_000; verbose::Int32 = 0; reserved::Int32 = 0
+    subsolver_maxit::Int64 = 1_000_000_000; verbose::Int32 = 0; warm_start::Int32 = 0
 end
 Base.@kwdef mutable struct AlpsStats
     tot_it::Int64 = 0; tot_inner_it::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; reserved::Int32 = 0
@@ -222,13 +223,15 @@ end
 """`PANOCplus(; directions=LBFGS(5), maxit, tol, verbose, freq, minimum_gamma, ...)` — same keywords
 as ProximalAlgorithms.PANOCplus as the reference configures it (demo/rosenbrock.jl:109-115)."""
 function PANOCplus(; directions = nothing, maxit = 1000, tol = 1e-8, verbose = false, freq = 10,
-                   minimum_gamma = 1e-7, alpha = 0.95, beta = 0.5, max_backtracks = 20, kwargs...)
+                   minimum_gamma = 1e-7, alpha = 0.95, beta = 0.5, max_backtracks = 20,
+                   Lf = nothing, gamma = Lf === nothing ? nothing : alpha / Lf, adaptive = gamma === nothing, kwargs...)
     M = directions === nothing ? 5 : directions.memory
     compact = !(directions isa LBFGS) || directions.compact === nothing ? 2 : Int(directions.compact)
     PANOCplusHIP(PanocOpts(tol = tol, maxit = min(maxit, typemax(Int64)), freq = min(freq, typemax(Int32)),
                            verbose = verbose, minimum_gamma = minimum_gamma, alpha = alpha, beta = beta,
                            max_backtracks = max_backtracks, lbfgs_memory = M, lbfgs_compact = compact,
-                           affine_refresh = get(kwargs, :affine_refresh, 8)))
+                           affine_refresh = get(kwargs, :affine_refresh, 8),
+                           gamma = gamma === nothing ? 0.0 : gamma, Lf = Lf === nothing ? 0.0 : Lf, adaptive = Int32(adaptive)))
 end
 
 # one device problem per live AugLagFun; the entry (and, through the finalizer, the device buffers) goes with the functor
@@ -252,15 +255,16 @@ end
 const _status = (:first_order, :max_iter, :exception, :unknown)          # alps.jl:105-113
 
 """`alps(f, g, c, D, x0, y0; kw...)`: same keywords, defaults and 10-tuple as `Bazinga.alps` (alps.jl:14-25,115);
-only scalars cross PCIe between subproblems."""
+only scalars cross PCIe between subproblems.  `warm_start = true` (not a keyword of the reference; default `false` = alps.jl:64)
+starts every subproblem after the first at the step size the previous one ended with."""
 function alps(f, g, c, D, x0::AbstractVector{T}, y0::AbstractVector{T}; tol::Real = T(1e-6), tol_prim::Real = tol,
               tol_dual::Real = tol, inner_tol::Real = cbrt(tol_dual), maxit::Integer = 100,
               theta_penalty::Real = 0.8, kappa_penalty::Real = 0.5, kappa_tol::Real = 0.1, verbose::Bool = false,
-              subsolver = PANOCplus, subsolver_maxit::Integer = 1_000_000_000) where {T}
+              subsolver = PANOCplus, subsolver_maxit::Integer = 1_000_000_000, warm_start::Bool = false) where {T}
     p = Problem(f, g, c, D, length(x0), length(y0), T)
     ao = AlpsOpts(tol_prim = tol_prim, tol_dual = tol_dual, inner_tol = inner_tol, maxit = maxit,
                   theta_penalty = theta_penalty, kappa_penalty = kappa_penalty, kappa_tol = kappa_tol,
-                  subsolver_maxit = subsolver_maxit, verbose = verbose)
+                  subsolver_maxit = subsolver_maxit, verbose = verbose, warm_start = Int32(warm_start))
     po = subsolver(tol = inner_tol, verbose = verbose).opts
     x = similar(x0); y = similar(y0); s = similar(y0); mu = similar(y0); st = Ref(AlpsStats())
     check(ccall((:bz_alps_solve, lib), Cint,

@@ -1216,9 +1216,13 @@ default_subsolver = PANOCplus
 def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol=None,
          maxit=100, theta_penalty=0.8, kappa_penalty=0.5, kappa_tol=0.1, verbose=False,
          dual_safeguard=default_dual_safeguard, subsolver=default_subsolver,
-         subsolver_maxit=1_000_000_000, outer_trace=None):
+         subsolver_maxit=1_000_000_000, outer_trace=None, warm_start=False):
     """alps.jl:7-117.  Returns the 10-tuple
-    (x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu)."""
+    (x, y, tot_it, tot_inner_it, elapsed_time, status, inner_tol, norm_res_prim, s, mu).
+
+    warm_start (NOT in the reference, False = alps.jl:64 as written): from the second subproblem on
+    ``subsolver(tol=…, verbose=…, gamma=γ_prev, adaptive=true)`` with the step size the previous subproblem ended
+    with — upstream's own `gamma` / `adaptive` keywords of PANOCplus, no Lipschitz estimate."""
     start_time = time.time()
     T = x0.dtype.type
     if tol is None:
@@ -1255,12 +1259,18 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         print(f"[ Info: initial inner tolerance {inner_tol}")
 
     can_stop = solved or tired or broken
+    gamma_prev = None
     while not can_stop:
         tot_it += 1
         dual_safeguard(y, cx)                                 # :62
-        sub_solver = subsolver(tol=inner_tol, verbose=verbose)  # :64
+        if warm_start and gamma_prev is not None:
+            sub_solver = subsolver(tol=inner_tol, verbose=verbose, gamma=gamma_prev, adaptive=True)
+        else:
+            sub_solver = subsolver(tol=inner_tol, verbose=verbose)  # :64
         AugLagUpdate(alFun, mu, y)                            # :65
         sub_sol, sub_it = sub_solver(f=alFun, g=gFun, x0=x)   # :66
+        if getattr(sub_solver, "last_state", None) is not None:
+            gamma_prev = sub_solver.last_state.gamma
         x[...] = sub_sol
         objx = alFun.fx + gFun.gz                             # :68
         tot_inner_it += sub_it

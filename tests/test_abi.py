@@ -71,11 +71,14 @@ def test_defaults_mirror_the_reference(bz):
     L.load().bz_panoc_default_opts(C.byref(o))
     assert (o.tol, o.maxit, o.freq, o.minimum_gamma, o.alpha, o.beta, o.max_backtracks, o.lbfgs_memory) == \
         (1e-8, 1000, 10, 1e-7, 0.95, 0.5, 20, 5)
+    # upstream: Lf = nothing, gamma = nothing, adaptive = (gamma === nothing)
+    assert (o.gamma, o.Lf, o.adaptive) == (0.0, 0.0, -1)
     a = L.AlpsOpts()
     L.load().bz_alps_default_opts(C.byref(a), L.BZ_F64)
     # src/algorithms/alps.jl:14-25
     assert a.tol_prim == 1e-6 and a.tol_dual == 1e-6 and abs(a.inner_tol - 1e-2) < 1e-15
     assert (a.maxit, a.theta_penalty, a.kappa_penalty, a.kappa_tol, a.subsolver_maxit) == (100, 0.8, 0.5, 0.1, 10 ** 9)
+    assert a.warm_start == 0          # alps.jl:64 as written unless the caller opts in
 
 
 def _no_gpu():

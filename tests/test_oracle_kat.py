@@ -28,6 +28,43 @@ def test_lasso_kat_test_verbose():
     assert out[5] == "first_order"
 
 
+def test_lasso_kat_with_the_warm_started_outer_loop():
+    """warm-starting gamma across subproblems is an opt-in deviation from alps.jl:64 — the reference's own
+    KAT (test_verbose.jl:29,42-44) still holds with it, and from the second subproblem on no Lipschitz estimate is made."""
+    A = np.array([[1, -2, 3, -4, 5], [2, -1, 0, -1, 3], [-1, 0, 4, -3, 2], [-1, -1, -1, 1, 3]], float)
+    b = np.array([1, 2, 3, 4.0])
+    lam = 0.1 * np.max(np.abs(A.T @ b))
+    x_star = np.array([-3.877278911564627e-01, 0, 0, 2.174149659863943e-02, 6.168435374149660e-01])
+    made = []
+
+    class Sub(R.PANOCplus):
+        def __init__(self, **kw):
+            made.append(kw.get("gamma"))
+            super().__init__(**kw)
+    out = R.alps(R.LeastSquares(A, b), R.NormL1(lam), R.IdentityFunction(), R.FreeSet(), np.zeros(5), np.zeros(5),
+                 warm_start=True, subsolver=Sub)
+    assert np.max(np.abs(out[0] - x_star)) <= 1e-4 and out[2] < 10 and out[3] < 50 and out[5] == "first_order"
+    assert made[0] is None and all(g is not None and g > 0 for g in made[1:]) and len(made) == out[2] >= 2
+
+
+def test_given_step_size_keywords():
+    """upstream's `gamma` / `Lf` / `adaptive`: a given step size is kept unless `adaptive` is set"""
+    n = 50
+    rng = np.random.default_rng(0)
+    q, bb = rng.uniform(0.5, 4.0, n), rng.standard_normal(n)
+    f, g = R.DiagQuadratic(q, bb), R.NormL1(0.1)
+    for kw, g0, adaptive in ((dict(gamma=0.1), 0.1, False), (dict(Lf=4.0), 0.95 / 4.0, False),
+                             (dict(gamma=10.0, adaptive=True), 10.0, True)):
+        it = R.PANOCplusIteration(f, g, np.zeros(n), **kw)
+        st = it.init()
+        for _ in range(10):
+            st = it.step(st)
+        if adaptive:
+            assert st.gamma < g0 and st.n_gamma_halvings >= 1 and 0.95 / st.gamma >= 4.0 * 0.9
+        else:
+            assert st.gamma == g0 and st.n_gamma_halvings == 0
+
+
 @pytest.mark.parametrize("gkind", ["box", "free"])
 def test_nonconvex_qp_tiny(gkind):
     """test/problems/test_nonconvex_qp.jl:8-52"""

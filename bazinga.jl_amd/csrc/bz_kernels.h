@@ -1247,11 +1247,16 @@ struct XCollectArgs {
 // rank's copy, fold over the ranks, hand the total to the host.  The 32 scalars of an exchange travel
 // independently — every tagged word validates itself — so nothing serialises on one workgroup (a single
 // 1024-thread block doing all of it measured 9.6 us and delayed the host's view of the result by ~10 us more).
-static __global__ void __launch_bounds__(64) k_exchange_collect(XCollectArgs b) {      // one WAVE per scalar
+// (scalar i of the pack, by the 64 lanes of one wave; without mailboxes — a single rank with no p2p context — the
+// local fold goes straight to the host)
+__device__ __forceinline__ void exchange_collect_one(const XCollectArgs& b, const int i, const int tid) {
     const XchgArgs& a = b.x;
-    const int tid = threadIdx.x, i = blockIdx.x;
     const bool ismax = (a.maxmask >> i) & 1u;
     double t = fold_wave(a.parts + (size_t)(a.first + i) * PSTRIDE, a.counts.get(i), ismax);
+    if (!a.mbox_local) {
+        if (tid == 0) host_post(b.host_out, i, t, b.ticket);
+        return;
+    }
     if (a.rank != 0 && !((a.keepmask >> i) & 1u)) t = 0.0;
     const int par = (int)(a.seq & 1ull);
     const unsigned long long tag = (unsigned long long)ll_tag(a.seq) << 32;
@@ -1282,6 +1287,9 @@ static __global__ void __launch_bounds__(64) k_exchange_collect(XCollectArgs b) 
         g = ismax ? nanmax(g, vr) : g + vr;
     }
     if (tid == 0) host_post(b.host_out, i, g, b.ticket);
+}
+static __global__ void __launch_bounds__(64) k_exchange_collect(XCollectArgs b) {      // one WAVE per scalar
+    exchange_collect_one(b, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // Halo exchange of the row-block-sharded stencil: this rank's first grid row goes to the previous rank's
@@ -2077,6 +2085,13 @@ template <int MM> struct CompactCoef {
     int keepx;                 // experiment (BZ_KEEPX): x_d is stored and x loaded with the default cache policy while every
                                // other stream stays non-temporal, so that the iterate written by one pass may be served from
                                // the Infinity Cache to the next
+    // read-back folded into the gated launch (fold_n != 0): before it goes to its gate, the first wave of workgroup i folds
+    // scalar i of the PREVIOUS pass (exchanges it with the other ranks' through the mailboxes, if any) and posts it to the
+    // host — the work of k_collect_w / k_exchange_collect without their launch: one kernel boundary and one small
+    // kernel's ramp less between two passes
+    int fold_n;
+    int gate_late;             // the pipelined form goes to its gate AFTER issuing the loads of its first packs
+    XCollectArgs fold;
 };
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
@@ -2492,10 +2507,18 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     compact_coefs<T, MM>(C, u1, u2h);
     T H0 = (T)C.H0;
     T gl = gamma * P.g_lambda;
+    __shared__ unsigned long long gate_sh;
+    // the previous pass's read-back, folded into this launch (one wave per scalar, spread over the workgroups): first
+    // thing in the kernel — the host's turn-around starts when these scalars arrive
     if constexpr (XR == 2) {
+        if (C.gate_seq != 0ull && C.fold_n && threadIdx.x < 64)
+            for (int i = (int)blockIdx.x; i < C.fold_n; i += (int)gridDim.x) exchange_collect_one(C.fold, i, (int)threadIdx.x);
+    }
+    // the gate of a pre-launched pass (see GateRec); returns false when the host recalled the launch
+    auto gate_wait = [&]() -> bool {
+        if constexpr (XR == 2) {
         if (C.gate_seq != 0ull) {
             static_assert(MM <= 5, "GateRec holds five coefficients of each kind");
-            __shared__ unsigned long long gate_sh;
             const unsigned long long tag = (unsigned long long)ll_tag(C.gate_seq) << 32;
             if (threadIdx.x < 64) {
                 const int lane = threadIdx.x;
@@ -2533,7 +2556,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                 if (lane == 0) gate_sh = sq;
             }
             __syncthreads();
-            if (gate_sh & GATE_ABORT) return;
+            if (gate_sh & GATE_ABORT) return false;
             // this kernel may have been resident while the previous pass (another stream) was still writing what it
             // is about to read: every wave takes an agent-scope acquire before its first load
             if (C.gate_other_stream) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -2545,7 +2568,15 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             H0 = (T)__hip_atomic_load(&C.gate_dev->val[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             z = (T*)(uintptr_t)__double_as_longlong(__hip_atomic_load(&C.gate_dev->val[11], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-    }
+        }
+        return true;
+    };
+    // the pipelined form issues the loads of its first packs BEFORE it goes to the gate (they do not depend on the
+    // coefficients): the gate wait hides their latency.  Not when the launch may be resident while the previous pass
+    // still writes (other stream): its first load must come after the acquire.
+    constexpr bool PIPE_ = SPEC && OFF32 && XR == 2;
+    const bool gate_late = PIPE_ && !C.gate_other_stream && C.gate_late;
+    if (!gate_late) { if (!gate_wait()) return; }
     if (SPEC && !OFF32) {      // keep the per-application coefficients in vector registers: scalar ones are the scarce kind here
 #pragma unroll
         for (int i = 0; i < MM; ++i) { asm volatile("" : "+v"(u1[i])); asm volatile("" : "+v"(u2h[i])); }
@@ -2777,6 +2808,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             // (three stages used in rotation, the loop unrolled by three: no register copies between iterations)
             Stage sc;
             if (c < nfull) { fetch(sa, c); fetch(sb, c + stride); }
+            if (gate_late) { if (!gate_wait()) return; }
             for (;;) {
                 if (c >= nfull) break;
                 fetch(sc, c + 2 * stride); use(sa, c); c += stride;
@@ -2787,6 +2819,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         } else {
             if (c < nfull) fetch(sa, c);
+            if (gate_late) { if (!gate_wait()) return; }
             for (;;) {
                 if (c >= nfull) break;
                 fetch(sb, c + stride); use(sa, c); c += stride;

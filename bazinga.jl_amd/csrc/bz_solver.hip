@@ -1020,10 +1020,14 @@ template <class T> class Solver final : public SolverBase {
         }
     }
     // launch the NEXT iteration's pass now, gated on the host record
-    void gate_prelaunch(const GatePlan& pl) {
+    // (fold: the read-back of the CURRENT pass's scalars rides in the early launch, see CompactCoef::fold)
+    void gate_prelaunch(const GatePlan& pl, const XCollectArgs* fold = nullptr, int fold_n = 0) {
         gate_alloc();
         CompactCoef<CM> C2;
         std::memset(&C2, 0, sizeof(C2));
+        if (fold) { C2.fold = *fold; C2.fold_n = fold_n; }
+        static const int glate_env = std::getenv("BZ_GATELATE") ? std::atoi(std::getenv("BZ_GATELATE")) : 1;
+        C2.gate_late = glate_env;
         C2.gate_seq = ++gate_seq_; C2.gate_host = gate_host_dev_; C2.gate_dev = gate_dev_.p; C2.gate_timeout = ptimeout_dev_;
         const int streams = (pl.m_now + 1) + pstreams(true, true, true) - (pl.uni >= 1 ? 1 : 0) - (pl.uni >= 2 ? 1 : 0) + 1;
         mv(streams);
@@ -1355,23 +1359,32 @@ template <class T> class Solver final : public SolverBase {
                               ctx->comm, cur_));
         for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
     }
-    // p2p transport: k_exchange and the read-back in one launch; returns the ticket wait_host must see
-    unsigned long long exchange_collect(int first, int cnt, unsigned maxmask) {
+    // the arguments of the fold + (p2p) exchange + read-back of slots [first, first + cnt): with mailboxes the exchange over
+    // the ranks, without (one rank, no p2p context) the local fold alone
+    XCollectArgs make_xcollect(int first, int cnt, unsigned maxmask) {
         if (cnt > P2P_PACK) throw Error(BZ_ERR_ARG, "pack too large for the p2p mailbox");
         XCollectArgs b;
         std::memset(&b, 0, sizeof(b));
         XchgArgs& a = b.x;
         a.parts = parts_.p; a.first = first; a.cnt = cnt; a.maxmask = maxmask;
         for (int i = 0; i < cnt; ++i) a.counts.set(i, slot_n[first + i]);
-        a.rank = ctx->rank; a.nranks = ctx->nranks; a.seq = ++ctx->xseq;
-        a.recv = recv_.p + (size_t)first * ctx->nranks;
-        a.mbox_local = (P2PWords*)ctx->mbox_local;
-        for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
+        a.rank = 0; a.nranks = 1;
+        if (ctx->p2p_on) {
+            a.rank = ctx->rank; a.nranks = ctx->nranks; a.seq = ++ctx->xseq;
+            a.recv = recv_.p + (size_t)first * ctx->nranks;
+            a.mbox_local = (P2PWords*)ctx->mbox_local;
+            for (int r = 0; r < ctx->nranks; ++r) a.mbox_peer[r] = (P2PWords*)ctx->mbox_peer[r];
+            for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
+        }
         a.timeout = ptimeout_dev_; a.keepmask = ~0u;
         b.host_out = host_out_dev_;
         b.ticket = ++collect_seq;
+        return b;
+    }
+    // p2p transport: k_exchange and the read-back in one launch; returns the ticket wait_host must see
+    unsigned long long exchange_collect(int first, int cnt, unsigned maxmask) {
+        XCollectArgs b = make_xcollect(first, cnt, maxmask);
         launch_b(C_GATHER, k_exchange_collect, cnt, 64, b);
-        for (int s = first; s < first + cnt; ++s) { grp_first[s] = first; grp_cnt[s] = cnt; }
         return b.ticket;
     }
     ScalarSrc src(int slot) const {
@@ -2383,25 +2396,38 @@ template <class T> class Solver final : public SolverBase {
             }
 #undef BZ_LAUNCH_FC3
 #undef BZ_LAUNCH_FC
-            if (ctx->p2p_on) {
-                // exchange + fold over the ranks + read-back in one launch (no k_collect)
-                tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
-                tail_used = true;
-            } else {
-                gather(SL_TRIAL, NFC, 1u << 9);
-                if (xr == 2 && gate_env_) {      // the read-back kernel now, so that the next pass can queue right behind it
-                    tail_ticket = collect_launch_range(SL_TRIAL, NFC, 1u << 9);
-                    tail_used = true;
-                }
-            }
+            // the NEXT iteration's pass, assuming this one ends the plain way (trial accepted, pair inserted, same gamma):
+            // ring one step on, one more pair
+            GatePlan nxt;
+            bool have_plan = false;
             if (xr == 2 && gate_env_ && more_coming_ && !opt.verbose && !prof_would_pick(C_FUSED_IT)) {
-                // the NEXT iteration's pass, assuming this one ends the plain way (trial accepted, pair inserted, same
-                // gamma): ring one step on, one more pair
                 double gr[NXR];
                 for (int i = 0; i < NXR; ++i) gr[i] = gring_[i];
                 gr[xd] = (double)gamma;
-                GatePlan nxt;
-                if (gate_make_plan(xd, std::min(m_now + 1, M), gr, xr_run_ + 1, nxt)) gate_prelaunch(nxt);
+                have_plan = gate_make_plan(xd, std::min(m_now + 1, M), gr, xr_run_ + 1, nxt);
+            }
+            // (BZ_GATEFOLD=1, off by default: measured no gain — the fold inside a 256-workgroup launch takes as long as the
+            // small read-back kernel and its boundary did: 29.5-31 us per iteration at n = 1.25e6 either way, NEXT.md)
+            static const int gfold_env = std::getenv("BZ_GATEFOLD") ? std::atoi(std::getenv("BZ_GATEFOLD")) : 0;
+            if (have_plan && gfold_env && gate_env_ == 1 && (!ctx->multi() || ctx->p2p_on)) {
+                // ... and this pass's read-back (with its exchange over the ranks) rides in that launch: no k_collect_w /
+                // k_exchange_collect kernel between the two passes
+                const XCollectArgs fold = make_xcollect(SL_TRIAL, NFC, 1u << 9);
+                tail_ticket = fold.ticket; tail_used = true;
+                gate_prelaunch(nxt, &fold, NFC);
+            } else {
+                if (ctx->p2p_on) {
+                    // exchange + fold over the ranks + read-back in one launch (no k_collect)
+                    tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
+                    tail_used = true;
+                } else {
+                    gather(SL_TRIAL, NFC, 1u << 9);
+                    if (xr == 2 && gate_env_) {      // the read-back kernel now, so that the next pass can queue right behind it
+                        tail_ticket = collect_launch_range(SL_TRIAL, NFC, 1u << 9);
+                        tail_used = true;
+                    }
+                }
+                if (have_plan) gate_prelaunch(nxt);
             }
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
             n_grad += 2; n_prox += 1;

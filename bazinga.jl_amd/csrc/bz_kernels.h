@@ -47,7 +47,9 @@ template <class T> struct alignas(16) Pack {
 
 // problem data every element-wise kernel may need (device pointers)
 template <class T> struct ElemParams {
-    int f_kind, g_kind, D_kind, pad;
+    int f_kind, g_kind, D_kind;
+    int uni;               // 0: mu and mu*y are streamed; 1: every mu[i] is mu_uniform (not streamed); 2: and mu*y = 0 — set only in
+                           // the copy handed to kernels that take them as numbers (same operands, same operations, same bits)
     const T* q;
     const T* b;
     const T* mu;
@@ -520,8 +522,8 @@ __device__ __forceinline__ void load_params(const ElemParams<T>& P, int64_t i0, 
     L.q = splat(T(0)); L.b = splat(T(0));
     if (need_f && P.f_kind == BZ_F_DIAG_QUADRATIC) { L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt); }
     if (need_al) {
-        L.mu = ldp<T, NT>(P.mu, i0, cnt);
-        L.muy = ldp<T, NT>(P.muy, i0, cnt);
+        L.mu = P.uni >= 1 ? splat(P.mu_uniform) : ldp<T, NT>(P.mu, i0, cnt);
+        L.muy = P.uni >= 2 ? splat(T(0)) : ldp<T, NT>(P.muy, i0, cnt);
         L.dlo = P.D_lo_vec ? ldp<T, NT>(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
         L.dhi = P.D_hi_vec ? ldp<T, NT>(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
     }

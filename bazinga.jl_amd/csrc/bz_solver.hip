@@ -1650,7 +1650,8 @@ template <class T> class Solver final : public SolverBase {
         // in D, alps.jl:97 scales them alike, and y0 = 0 holds through the first subproblem — the longest one.
         uni_ = 0;
         const int uni_env = std::getenv("BZ_UNI") ? std::atoi(std::getenv("BZ_UNI")) : 2;      // (tests toggle it)
-        const bool probe = uni_env && fused_family() >= 0;
+        const bool probe = uni_env && (fused_family() >= 0 ||
+                                       (desc.f_kind == BZ_F_STENCIL5 && desc.c_kind == BZ_C_IDENTITY && !slack && !lp_g));
         for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
         slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
         mv(3 + (safeguard ? 1 : 0), ny);
@@ -2467,26 +2468,31 @@ template <class T> class Solver final : public SolverBase {
                 // stencil fast path: {AL gradient at x_d + FB step} and {AL gradient at z + pair + stop norm}
                 // as two passes; same partial sums as the four generic kernels of the first trial
                 for (int sidx = SL_FXD; sidx <= SL_STOP; ++sidx) slot_n[sidx] = grid;
-                mv(2 + pstreams(false, true, true) + 3);        // x_d, b + parameters ; grad, z, res
+                // uniform penalties / zero multipliers travel as numbers here too (k_uniform_probe at AugLagUpdate!): the
+                // two stencil passes stream mu and mu*y otherwise — 4 of the iteration's 43 passes
+                ElemParams<T> Pu = P;
+                Pu.uni = uni_;
+                const int uni_saved = (uni_ >= 1 ? 1 : 0) + (uni_ >= 2 ? 1 : 0);
+                mv(2 + pstreams(false, true, true) - uni_saved + 3);        // x_d, b + parameters ; grad, z, res
                 nm("k_stencil_fb");
                 const StencilHalo<T> halo_x = halo_exchange(X_[xd].p);
                 static const int fbnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
                 if (fbnt_env && (double)n * sizeof(T) * 12 > 340e6)
-                    launch(C_STENCIL_FB, k_stencil_fb<T, true>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
+                    launch(C_STENCIL_FB, k_stencil_fb<T, true>, grid, (const T*)X_[xd].p, Pu, (int64_t)desc.f_grid_nx,
                            (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                            (int)SL_GSUM, halo_x);
                 else
-                launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
+                launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, Pu, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                        (int)SL_GSUM, halo_x);
                 const StencilHalo<T> halo_z = halo_exchange(Z_[zn].p);
                 if (use_compact) {
                     // ... with the Gram products of the new pair and the next application's p, w in the same pass
                     for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
-                    mv(2 + pstreams(false, true, false) + 5 + 2 + 2 * CV.m);
+                    mv(2 + pstreams(false, true, false) - uni_saved + 5 + 2 + 2 * CV.m);
                     nm("k_stencil_update_c");
 #define BZ_LAUNCH_SUC(FULL_, NT_)                                                                                 \
-    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
+    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_>, grid, CV, (const T*)Z_[zn].p, Pu, (int64_t)desc.f_grid_nx, \
            (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p, (const T*)RES_[rp].p, \
            (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL, halo_z)
                     {
@@ -2504,9 +2510,9 @@ template <class T> class Solver final : public SolverBase {
                     }
                     gram_from_trial = true;
                 } else {
-                mv(2 + pstreams(false, true, false) + 5 + 2);   // z, b + parameters, x_d, x, res, res_prev, grad ; s, y
+                mv(2 + pstreams(false, true, false) - uni_saved + 5 + 2);   // z, b + parameters, x_d, x, res, res_prev, grad ; s, y
                 nm("k_stencil_update");
-                launch(C_STENCIL_UPD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
+                launch(C_STENCIL_UPD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, Pu, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
                        (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, (T*)nullptr, n, parts_.p,
                        (int)SL_FZ, (int)SL_YS, halo_z);

@@ -437,6 +437,17 @@ def repeat_blocks(first_elapsed, steps, one_block):
             "note": "the K-step block lasts < 100 ms: repeated from a fresh solve with the same warm-up; `value` is block 1"}
 
 
+def event_period(steps):
+    """Sampling period of the in-library HIP events inside the timed region.  A launch that carries a start / stop event pair
+    costs ~8 us more than a plain one (measured on cfg 3: 247.2 us per iteration with every 2nd launch timed, 238.2 with
+    every 8th, 233.2 with every 32nd, 232.5 with none) and is never pre-launched behind its gate, so the timed region
+    samples sparsely: about a dozen launches per kernel and K-step block (every 16th at the default K = 200: < 0.5 % of
+    the block), never fewer than every 4th nor more than every 32nd.  BZ_BENCH_PERIOD overrides."""
+    if os.environ.get("BZ_BENCH_PERIOD"):
+        return int(os.environ["BZ_BENCH_PERIOD"])
+    return int(max(4, min(32, steps // 12)))
+
+
 def side_workload(args):
     """cfg 3 / cfg 4 (single GPU): the other BASELINE configs, same JSON shape; not the headline."""
     import bazinga_jl_amd as bz
@@ -472,7 +483,7 @@ def side_workload(args):
     note(f"{args.workload}: warm-up {args.warmup} + {args.steps} timed iterations")
     fresh()
     prob.profile_reset()
-    prob.profile_enable(True, period=int(os.environ.get("BZ_BENCH_PERIOD", "2")))
+    prob.profile_enable(True, period=event_period(args.steps))
     elapsed = run_block(prob, args.steps, None)
     prob.profile_enable(False)
     prof = prob.profile2()
@@ -745,7 +756,7 @@ def main():
             mask = 1 << bz._lib.KERNEL_CATEGORIES.index(dom)
             if dom in FUSED_FORMS:      # both forms of the one-pass kernel: which one dominates is only known afterwards
                 mask = sum(1 << bz._lib.KERNEL_CATEGORIES.index(k) for k in FUSED_FORMS)
-            prob.profile_enable(mask, period=int(os.environ.get("BZ_BENCH_PERIOD", "8")))
+            prob.profile_enable(mask, period=event_period(steps))
             st0 = prob.panoc_stats()
         except Exception as e:      # noqa: BLE001
             ok, err = 0, repr(e)[:300]

@@ -48,8 +48,8 @@ template <class T> struct alignas(16) Pack {
 // problem data every element-wise kernel may need (device pointers)
 template <class T> struct ElemParams {
     int f_kind, g_kind, D_kind;
-    int uni;               // 0: mu and mu*y are streamed; 1: every mu[i] is mu_uniform (not streamed); 2: and mu*y = 0 — set only in
-                           // the copy handed to kernels that take them as numbers (same operands, same operations, same bits)
+    int uni;               // 0: mu and mu*y are streamed; 1: every mu[i] is mu_uniform: a number, not a stream; 2: and mu*y = 0
+                           // (k_muy's probe at every AugLagUpdate!; same operands, same operations, same bits)
     const T* q;
     const T* b;
     const T* mu;
@@ -2065,7 +2065,11 @@ struct GateRec {
     double val[13];
 };
 constexpr unsigned long long GATE_ABORT = 1ull << 63;
-constexpr unsigned GATE_SPIN_HOST = 150000u, GATE_SPIN_DEV = 300000u;      // ~0.2 s each
+// Workgroup 0 gives up on the host after ~3 s (a host thread that was merely descheduled comes back long before; the
+// launch then leaves as a whole — ABORT for everybody — and the host reports it).  The other workgroups never take a
+// decision of their own: they wait for workgroup 0's verdict, and their (much longer) bound is only there so that no wave
+// can spin forever; reaching it is an error the host reports, never a silently skipped part of the pass.
+constexpr unsigned GATE_SPIN_HOST = 2500000u, GATE_SPIN_DEV = 60000000u;
 
 template <int MM> struct CompactCoef {
     // coefficients of this application, computed by the host from p = S'v, w = Y'v (v = -res) and the Gram
@@ -2091,6 +2095,7 @@ template <int MM> struct CompactCoef {
     // scalar i of the PREVIOUS pass (exchanges it with the other ranks' through the mailboxes, if any) and posts it to the
     // host — the work of k_collect_w / k_exchange_collect without their launch: one kernel boundary and one small
     // kernel's ramp less between two passes
+    unsigned gate_spin_host, gate_spin_dev;      // poll bounds of workgroup 0 (host record) and of the others (device flag)
     int fold_n;
     int gate_late;             // the pipelined form goes to its gate AFTER issuing the loads of its first packs
     XCollectArgs fold;
@@ -2535,7 +2540,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                         if (ok & (1ull << 31)) { sq = C.gate_seq | GATE_ABORT; break; }
                         if ((ok & 0x3FFFFFFull) == 0x3FFFFFFull) { sq = C.gate_seq; break; }
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > GATE_SPIN_HOST) { sq = C.gate_seq | GATE_ABORT; if (lane == 0) *C.gate_timeout = 6; break; }
+                        if (++spins > C.gate_spin_host) { sq = C.gate_seq | GATE_ABORT; if (lane == 0) *C.gate_timeout = 6; break; }
                     }
                     // even lanes 0, 2, .., 24 assemble value lane/2 from their word and the next lane's
                     const unsigned lo = (unsigned)word, hi = (unsigned)__shfl((unsigned)word, lane + 1, 64);
@@ -2552,7 +2557,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
                         if ((sq & ~GATE_ABORT) == C.gate_seq) break;
                         // (other stream: ~0.7 us between polls — 255 pollers must not load the fabric while a pass streams)
                         if (C.gate_other_stream) __builtin_amdgcn_s_sleep(24); else __builtin_amdgcn_s_sleep(2);
-                        if (++spins > GATE_SPIN_DEV) { sq = C.gate_seq | GATE_ABORT; break; }
+                        if (++spins > C.gate_spin_dev) { sq = C.gate_seq | GATE_ABORT; *C.gate_timeout = 7; break; }
                     }
                 }
                 if (lane == 0) gate_sh = sq;
@@ -2648,8 +2653,8 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             for (int i = 0; i < MM; ++i) ps[i] = SG.ps[i];
         } else if constexpr (O32 && !FAMILY) {
             L.q = ldo<T, NT>(P.q, bo); L.b = ldo<T, NT>(P.b, bo);
-            L.mu = ldo<T, NT>(P.mu, bo);
-            L.muy = ldo<T, NT>(P.muy, bo);
+            if (P.uni >= 1) L.mu = splat(P.mu_uniform); else L.mu = ldo<T, NT>(P.mu, bo);
+            if (P.uni >= 2) L.muy = splat(T(0)); else L.muy = ldo<T, NT>(P.muy, bo);
             L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
             L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
             px = ldo<T, NT>(x, bo);
@@ -2662,8 +2667,8 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         } else {
             if (SPEC && !FAMILY) {
                 L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
-                L.mu = ldp<T, NT>(P.mu, i0, cnt);
-                L.muy = ldp<T, NT>(P.muy, i0, cnt);
+                if (P.uni >= 1) L.mu = splat(P.mu_uniform); else L.mu = ldp<T, NT>(P.mu, i0, cnt);
+                if (P.uni >= 2) L.muy = splat(T(0)); else L.muy = ldp<T, NT>(P.muy, i0, cnt);
                 L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi);
                 L.gu = splat(T(0)); L.glo = splat(T(0)); L.ghi = splat(T(0));
             } else {

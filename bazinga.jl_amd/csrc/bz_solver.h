@@ -54,6 +54,7 @@ struct Ctx {
     ncclComm_t comm = nullptr;
     // p2p
     bool p2p_on = false;
+    bool shared_device = false;            // another rank of this job runs on the same GPU (one-GPU rehearsals): no resident, polling launches
     P2PMailbox* mbox_local = nullptr;
     P2PMailbox* mbox_peer[P2P_MAXRANKS] = {};
     bool mbox_opened[P2P_MAXRANKS] = {};

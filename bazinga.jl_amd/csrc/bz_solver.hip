@@ -57,6 +57,7 @@ void p2p_connect(Ctx* ctx, const void* handles, const int32_t* devices) {
     const unsigned char* hs = (const unsigned char*)handles;
     for (int r = 0; r < ctx->nranks; ++r) {
         if (r == ctx->rank) { ctx->mbox_peer[r] = ctx->mbox_local; continue; }
+        if (devices && devices[r] == ctx->device) ctx->shared_device = true;
         if (devices && devices[r] != ctx->device) {
             hipError_t e = hipDeviceEnablePeerAccess(devices[r], 0);
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
@@ -92,6 +93,13 @@ __global__ void __launch_bounds__(64) k_collect_w(CollectArgs a, double* out) {
 
 // the persistent two-loop kernel's grid barrier gave up (its workgroups were not all resident): single-rank
 // solves catch this, switch to the kernel chain for good and redo the iteration
+// a pre-launched pass gave up at its gate (the host did not release it in time, or workgroup 0 was not resident in
+// time because somebody else holds the CUs): it has written nothing that the same pass, launched again, does not
+// write again — single-rank solves catch this, redo the iteration without the gate and leave the gate off
+struct GateTimeout : Error {
+    explicit GateTimeout(int code) : Error(BZ_ERR_COMM, code == 6 ? "a pre-launched pass timed out at its gate (the host never released it)"
+                                                                   : "a pre-launched pass: workgroups timed out waiting for workgroup 0 to open the gate") {}
+};
 struct PersistTimeout : Error {
     PersistTimeout() : Error(BZ_ERR_HIP, "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)") {}
 };
@@ -808,7 +816,7 @@ template <class T> class Solver final : public SolverBase {
         for (int i = 0; i < m; ++i) { V.S[i] = S_[order[m - 1 - i]].p; V.Y[i] = Y_[order[m - 1 - i]].p; }
         if (rh_stale_) {
             // (must run before gamma changes: the residuals are re-evaluated with the gamma of this run)
-            mv((m + 1) + 4 + 2 * m + 2);
+            mv((m + 1) + pstreams(true, true, true) + 2 * m + 2);
             launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, m, P, RES_[rc].p, Z_[zc].p, n);
             res_valid = true; z_valid = true;
         } else {
@@ -954,6 +962,9 @@ template <class T> class Solver final : public SolverBase {
     unsigned long long gate_seq_ = 0;
     bool gate_pending_ = false, more_coming_ = false;
     int gate_env_ = 1;
+    bool gate_broken_ = false;
+    int gate_sabotage_ = 0;                  // (test) the n-th release is withheld: the launch must time out at its gate
+    int64_t n_gate_fallbacks_ = 0;
     GatePlan gate_plan_{};
     double gate_bytes_ = 0.0;
     int64_t n_gated_ = 0, n_gate_aborts_ = 0;
@@ -989,7 +1000,7 @@ template <class T> class Solver final : public SolverBase {
         pl.x = X_[xc_].p; pl.xd = X_[(xc_ + 1) % NXR].p;
         pl.gamma = (double)gamma; pl.uni = uni_; pl.fam = fam; pl.m_now = m_now;
         pl.gfc = gfc_env_ > 0 ? std::min(grid, gfc_env_ * std::max(1, num_cus)) : std::min(grid, std::max(1, num_cus));
-        const int streams = (m_now + 1) + pstreams(true, true, true) - (uni_ >= 1 ? 1 : 0) - (uni_ >= 2 ? 1 : 0) + 1;
+        const int streams = (m_now + 1) + pstreams(true, true, true) + 1;      // (uniform penalties / zero multipliers are not streams)
         pl.nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * streams > 340e6;
         pl.table = !(spec_env && fam == FAM_HEADLINE) || famrt_env_;
         return true;
@@ -1028,8 +1039,12 @@ template <class T> class Solver final : public SolverBase {
         if (fold) { C2.fold = *fold; C2.fold_n = fold_n; }
         static const int glate_env = std::getenv("BZ_GATELATE") ? std::atoi(std::getenv("BZ_GATELATE")) : 1;
         C2.gate_late = glate_env;
+        // (BZ_GATE_SPIN: the poll bounds, for the test of the fall-back)
+        static const unsigned spin_env = std::getenv("BZ_GATE_SPIN") ? (unsigned)std::atoll(std::getenv("BZ_GATE_SPIN")) : 0u;
+        C2.gate_spin_host = spin_env ? spin_env : GATE_SPIN_HOST;
+        C2.gate_spin_dev = spin_env ? 8u * spin_env : GATE_SPIN_DEV;
         C2.gate_seq = ++gate_seq_; C2.gate_host = gate_host_dev_; C2.gate_dev = gate_dev_.p; C2.gate_timeout = ptimeout_dev_;
-        const int streams = (pl.m_now + 1) + pstreams(true, true, true) - (pl.uni >= 1 ? 1 : 0) - (pl.uni >= 2 ? 1 : 0) + 1;
+        const int streams = (pl.m_now + 1) + pstreams(true, true, true) + 1;
         mv(streams);
         gate_bytes_ = pending_bytes_;
         hipStream_t here = cur_;
@@ -1046,6 +1061,10 @@ template <class T> class Solver final : public SolverBase {
         gate_plan_ = pl; gate_pending_ = true;
     }
     void gate_release(const CompactCoef<CM>& C, T* zstore) {
+        if (gate_sabotage_ > 0 && --gate_sabotage_ == 0) {      // (test) forget this release: the launch times out at its gate
+            cur_ = gate_on_; gate_pending_ = false; ++n_gated_;
+            return;
+        }
         // 12 values (u1, u2h, H0, the z address) as tagged half-words: any order, each word validates itself
         double vals[13] = {0};
         for (int i = 0; i < CM; ++i) { vals[i] = C.u1[i]; vals[5 + i] = C.u2h[i]; }
@@ -1094,7 +1113,7 @@ template <class T> class Solver final : public SolverBase {
     int pstreams(bool need_f, bool need_al, bool need_g) const {
         int k = 0;
         if (need_f && P.f_kind == BZ_F_DIAG_QUADRATIC) k += 2;
-        if (need_al) k += 2 + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0);
+        if (need_al) k += 2 - (P.uni >= 1 ? 1 : 0) - (P.uni >= 2 ? 1 : 0) + (P.D_lo_vec ? 1 : 0) + (P.D_hi_vec ? 1 : 0);
         if (need_g) k += (P.g_u && (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX || P.g_kind == BZ_G_NORM_LP_BOX) ? 1 : 0) +
                          (P.g_lo_vec ? 1 : 0) + (P.g_hi_vec ? 1 : 0);
         return k;
@@ -1457,12 +1476,14 @@ template <class T> class Solver final : public SolverBase {
             const int code = *ptimeout_;
             *ptimeout_ = 0;
             if (code == 1 && ctx->nranks == 1) throw PersistTimeout();
+            if (code == 6 || code == 7) throw GateTimeout(code);
             throw Error(code == 1 ? BZ_ERR_HIP : BZ_ERR_COMM,
                         code == 1 ? "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)"
                         : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
                         : code == 4 ? "stencil halo exchange timed out waiting for a neighbour rank"
                         : code == 5 ? "dense-constraint all-reduce timed out waiting for a peer rank"
                         : code == 6 ? "a pre-launched pass timed out at its gate (the host never released it)"
+                        : code == 7 ? "a pre-launched pass: workgroups timed out waiting for workgroup 0 to open the gate"
                                     : "persistent two-loop kernel: p2p phase exchange timed out waiting for a peer rank");
         }
         std::vector<double> out(a.n);
@@ -1680,6 +1701,7 @@ template <class T> class Solver final : public SolverBase {
             uni_ = (u[2] == 0.0 && uni_env >= 2) ? 2 : 1;
             P.mu_uniform = (T)u[0];
         }
+        P.uni = uni_;      // every kernel that takes the penalties through load_params takes them as numbers then
     }
     // the oracle family of the iterate-history one-pass kernel (fam_code, bz_kernels.h), or -1: c = Identity, an
     // element-wise f, any element-wise g but the Newton / L0 kinds, any D
@@ -2062,6 +2084,10 @@ template <class T> class Solver final : public SolverBase {
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
         gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 1;
+        // a resident launch polling at its gate holds its CUs: with another tenant on the GPU (a rank of this very job in
+        // a one-GPU rehearsal, or whoever made an earlier launch of this problem miss its gate) the two starve each other
+        if (ctx->shared_device || gate_broken_) gate_env_ = 0;
+        gate_sabotage_ = std::getenv("BZ_TEST_GATE_TIMEOUT") ? std::atoi(std::getenv("BZ_TEST_GATE_TIMEOUT")) : 0;
         if (gate_env_ && fused_ok) gate_alloc();      // (pinned record, device copy, second stream: not inside an iteration)
         gate_quiesce();
         if (x0_dev != X_[0].p)
@@ -2215,6 +2241,18 @@ template <class T> class Solver final : public SolverBase {
         const unsigned long long sv_pseq = ctx->pseq;
         try {
             step_impl();
+        } catch (const GateTimeout&) {
+            // (several ranks: the others have taken this rank's stale scalars for good ones — not recoverable here)
+            if (ctx->nranks > 1) throw;
+            gate_abort();              // (the pass launched early for the iteration after this one)
+            BZ_HIP(hipStreamSynchronize(cur_));
+            cur_ = ctx->stream;
+            *ptimeout_ = 0;
+            k_ = sv[0]; n_grad = sv[1]; n_prox = sv[2]; n_bt = sv[3]; n_halv = sv[4]; n_fused = sv[5]; n_skips = sv[6];
+            gx_valid = false; gz_valid = false;
+            gate_broken_ = true; gate_env_ = 0; ++n_gate_fallbacks_;
+            std::fprintf(stderr, "Warning: a pre-launched pass timed out at its gate (is the GPU shared?); gated pre-launch is off for this problem\n");
+            step_impl();
         } catch (const PersistTimeout&) {
             BZ_HIP(hipStreamSynchronize(ctx->stream));
             *ptimeout_ = 0;
@@ -2327,7 +2365,7 @@ template <class T> class Solver final : public SolverBase {
             if (xr == 2 && gfc_env <= 0) gfc = std::min(grid, std::max(1, num_cus));
             for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
             // (the vectors this pass touches: history + x_d + z + the parameter vectors (+ res, s, y))
-            const int xr2_streams = (m_now + 1) + pstreams(true, true, true) - (uni >= 1 ? 1 : 0) - (uni >= 2 ? 1 : 0) + 1;
+            const int xr2_streams = (m_now + 1) + pstreams(true, true, true) + 1;      // (pstreams leaves out what travels as numbers)
             const int nvec = (xr == 2 ? xr2_streams : 2 * CM + 5 + pstreams(true, true, true)) + (zstore ? 1 : 0);
             const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * nvec > 340e6;
             if (gate_pending_ && xr != 2) gate_abort();
@@ -2369,7 +2407,7 @@ template <class T> class Solver final : public SolverBase {
                     XV.S[i] = X_[(xc - CM + i + NXR) % NXR].p;
                     XV.Y[i] = RES_[(rc - CM + i + NRR) % NRR].p;
                 }
-                mv(2 * (CM + 1) + 4 + 2 + (zstore ? 1 : 0));
+                mv(2 * (CM + 1) + pstreams(true, true, true) + 2 + (zstore ? 1 : 0));
                 form_[C_FUSED] = std::string("k_fused_compact<XR=1") + (nt ? ",NT=1>" : ",NT=0>");
                 if (nt)
                     launch(C_FUSED, k_fused_compact<T, CM, true, true, true, 1>, gfc, XV, CC, (const T*)X_[xp].p,
@@ -2468,31 +2506,28 @@ template <class T> class Solver final : public SolverBase {
                 // stencil fast path: {AL gradient at x_d + FB step} and {AL gradient at z + pair + stop norm}
                 // as two passes; same partial sums as the four generic kernels of the first trial
                 for (int sidx = SL_FXD; sidx <= SL_STOP; ++sidx) slot_n[sidx] = grid;
-                // uniform penalties / zero multipliers travel as numbers here too (k_uniform_probe at AugLagUpdate!): the
-                // two stencil passes stream mu and mu*y otherwise — 4 of the iteration's 43 passes
-                ElemParams<T> Pu = P;
-                Pu.uni = uni_;
-                const int uni_saved = (uni_ >= 1 ? 1 : 0) + (uni_ >= 2 ? 1 : 0);
-                mv(2 + pstreams(false, true, true) - uni_saved + 3);        // x_d, b + parameters ; grad, z, res
+                // (uniform penalties / zero multipliers travel as numbers, P.uni: the two stencil passes stream mu and mu*y
+                // otherwise — 4 of the iteration's 43 passes)
+                mv(2 + pstreams(false, true, true) + 3);        // x_d, b + parameters ; grad, z, res
                 nm("k_stencil_fb");
                 const StencilHalo<T> halo_x = halo_exchange(X_[xd].p);
                 static const int fbnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
                 if (fbnt_env && (double)n * sizeof(T) * 12 > 340e6)
-                    launch(C_STENCIL_FB, k_stencil_fb<T, true>, grid, (const T*)X_[xd].p, Pu, (int64_t)desc.f_grid_nx,
+                    launch(C_STENCIL_FB, k_stencil_fb<T, true>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
                            (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                            (int)SL_GSUM, halo_x);
                 else
-                launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, Pu, (int64_t)desc.f_grid_nx,
+                launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                        (int)SL_GSUM, halo_x);
                 const StencilHalo<T> halo_z = halo_exchange(Z_[zn].p);
                 if (use_compact) {
                     // ... with the Gram products of the new pair and the next application's p, w in the same pass
                     for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
-                    mv(2 + pstreams(false, true, false) - uni_saved + 5 + 2 + 2 * CV.m);
+                    mv(2 + pstreams(false, true, false) + 5 + 2 + 2 * CV.m);
                     nm("k_stencil_update_c");
 #define BZ_LAUNCH_SUC(FULL_, NT_)                                                                                 \
-    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_>, grid, CV, (const T*)Z_[zn].p, Pu, (int64_t)desc.f_grid_nx, \
+    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
            (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p, (const T*)RES_[rp].p, \
            (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL, halo_z)
                     {
@@ -2510,9 +2545,9 @@ template <class T> class Solver final : public SolverBase {
                     }
                     gram_from_trial = true;
                 } else {
-                mv(2 + pstreams(false, true, false) - uni_saved + 5 + 2);   // z, b + parameters, x_d, x, res, res_prev, grad ; s, y
+                mv(2 + pstreams(false, true, false) + 5 + 2);   // z, b + parameters, x_d, x, res, res_prev, grad ; s, y
                 nm("k_stencil_update");
-                launch(C_STENCIL_UPD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, Pu, (int64_t)desc.f_grid_nx,
+                launch(C_STENCIL_UPD, k_stencil_update<T>, grid, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx,
                        (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p,
                        (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, (T*)nullptr, n, parts_.p,
                        (int)SL_FZ, (int)SL_YS, halo_z);
@@ -2668,7 +2703,7 @@ template <class T> class Solver final : public SolverBase {
            (const T*)X_[xp].p, (const T*)nullptr, P, gamma, X_[xb].p, Z_[zn].p, RES_[rn].p, (T*)nullptr,         \
            (T*)nullptr, n, parts_.p, (int)SL_TRIAL)
                 // the iterates, the parameter vectors (mu, mu*y unless numbers), the trial point ; z, res
-                mv((m_at_trial + 1) + pstreams(true, true, true) - (trial_uni >= 1 ? 1 : 0) - (trial_uni >= 2 ? 1 : 0) + 1 + 2);
+                mv((m_at_trial + 1) + pstreams(true, true, true) + 1 + 2);
                 if (trial_table) {
                     trial_CC.uni_rt = trial_uni; trial_CC.trial_rt = 1;
                     FusedFn<T> fn = family_kernel<T>(trial_fam, trial_nt);
@@ -2774,6 +2809,7 @@ template <class T> class Solver final : public SolverBase {
         st->n_affine_images = n_affine_;
         st->n_gated_launches = n_gated_;
         st->n_gate_aborts = n_gate_aborts_;
+        st->n_gate_fallbacks = n_gate_fallbacks_;
     }
 };
 

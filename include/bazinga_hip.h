@@ -285,6 +285,10 @@ typedef struct {
                                  wherever the library itself runs the loop); ~6 us per iteration; BZ_GATE=0 turns
                                  it off                                                                           */
     int64_t n_gate_aborts;    /* ... and early launches recalled because the iteration did not end the plain way   */
+    int64_t n_gate_fallbacks; /* times an early launch gave up at its gate — the host did not release it within ~3 s, or its
+                                 first workgroup was not resident in time because another tenant holds the GPU's CUs —
+                                 and the iteration was redone without the gate, which then stays off for this problem
+                                 (0 or 1; one rank only: with several ranks it is BZ_ERR_COMM)                        */
 } bz_panoc_stats;
 
 /* Multipliers/penalties of the current subproblem:  AugLagUpdate!(alFun, mu, y)

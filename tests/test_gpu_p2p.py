@@ -97,6 +97,73 @@ def test_two_ranks_on_one_gpu_match_single_rank(bz, persist, compact):
         assert all(r[6] == 0 and r[7] > 5 * ITERS for r in res)
 
 
+def _worker_steps(rank, world, n_total, conn):
+    """as _worker, through bz_panoc_steps (the library runs the loop: the path bench.py times)"""
+    try:
+        sys.path.insert(0, ROOT)
+        import bazinga_jl_amd as bz
+        ctx = bz.Context(device=0, rank=rank, nranks=world, comm_id=None)
+        conn.send(ctx.p2p_export())
+        ctx.p2p_connect(conn.recv(), [0] * world)
+        lo, hi = bz.shard_bounds(n_total, rank, world)
+        d = bz.synth.l1_quadratic(hi - lo, start=lo)
+        nl = hi - lo
+        prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                          bz.ClosedSet(bz.IndBox(-1.0, 1.0)), nl, nl, np.float64, ctx)
+        prob.set_multipliers(np.full(nl, 0.1), np.zeros(nl))
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(nl))
+        for chunk in (3, 20, 17):
+            prob.panoc_steps(chunk)
+        st = prob.panoc_stats()
+        out = (rank, prob.panoc_vector("x"), prob.panoc_scalars(), (st.n_gated_launches, st.n_gate_fallbacks, st.n_fused_iters))
+        prob.close()
+        ctx.close()
+        conn.send(("ok", out))
+    except Exception as e:      # noqa: BLE001
+        conn.send(("error", repr(e)))
+
+
+@pytest.mark.timeout(600)
+def test_library_loop_two_ranks_on_one_gpu(bz):
+    """bz_panoc_steps with x sharded over two ranks that SHARE the GPU: the gated pre-launch must stay off there (a
+    resident launch polling at its gate holds its CUs, and two tenants doing that starve each other: before the contexts
+    knew that they share a device this configuration ran into the gate's poll bounds and, worse, went on with partly
+    executed passes), and the iterates are those of the single-rank solve."""
+    mpc = mp.get_context("spawn")
+    n_total = 1_000_000
+    pipes = [mpc.Pipe() for _ in range(2)]
+    procs = [mpc.Process(target=_worker_steps, args=(r, 2, n_total, pipes[r][1])) for r in range(2)]
+    for p in procs:
+        p.start()
+    handles = [pipes[r][0].recv() for r in range(2)]
+    for r in range(2):
+        pipes[r][0].send(handles)
+    res = []
+    for r in range(2):
+        assert pipes[r][0].poll(240), "rank did not answer"
+        status, payload = pipes[r][0].recv()
+        assert status == "ok", payload
+        res.append(payload)
+    for p in procs:
+        p.join(60)
+    res.sort(key=lambda t: t[0])
+    d = bz.synth.l1_quadratic(n_total)
+    prob = bz.Problem(bz.DiagQuadratic(d["q"], d["b"]), bz.NormL1(d["lam"]), bz.IdentityFunction(),
+                      bz.ClosedSet(bz.IndBox(-1.0, 1.0)), n_total, n_total, np.float64)
+    prob.set_multipliers(np.full(n_total, 0.1), np.zeros(n_total))
+    prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n_total))
+    prob.panoc_steps(40)
+    x1, s1, st1 = prob.panoc_vector("x"), prob.panoc_scalars(), prob.panoc_stats()
+    prob.close()
+    assert st1.n_gated_launches >= 30                   # one tenant: the gate is in use
+    x = np.concatenate([r[1] for r in res])
+    assert np.max(np.abs(x - x1)) <= 1e-10 * np.max(np.abs(x1))
+    for key in ("gamma", "f_x", "stop_norm", "FBE"):
+        assert res[0][2][key] == res[1][2][key]
+    assert abs(res[0][2]["stop_norm"] - s1["stop_norm"]) <= 1e-8 * max(1.0, s1["stop_norm"])
+    assert all(r[3][0] == 0 and r[3][1] == 0 and r[3][2] >= 38 for r in res)
+
+
 @pytest.mark.timeout(600)
 def test_unequal_shards_take_the_same_two_loop_form(bz):
     """Shards that straddle the persistent kernel's size threshold (300 032 and 299 967 elements around

@@ -1474,3 +1474,37 @@ def test_gated_prelaunch_is_bitwise_neutral(bz, ref, fam, monkeypatch):
         monkeypatch.setenv("BZ_GATE", gate)
         outs.append(bz.alps(*dev, np.zeros(n), np.zeros(n)))
     assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3] and np.array_equal(outs[0][0], outs[1][0])
+
+
+def test_gate_timeout_falls_back_to_plain_launches(bz, ref, monkeypatch):
+    """A pre-launched pass that is not released in time (a stalled host thread; another tenant on the GPU keeping its
+    first workgroup from becoming resident) leaves as a whole, the host redoes the iteration with a plain launch and keeps
+    the gate off for the problem: the same bits as a solve that never used the gate, one fall-back in the statistics.
+    (BZ_TEST_GATE_TIMEOUT=k: the k-th release is withheld; BZ_GATE_SPIN shortens the poll bounds from ~3 s.)"""
+    n = 300_007
+    d, dev, orc = make_cfg2(bz, ref, n)
+    mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
+    runs = []
+    for gate, sab in (("0", "0"), ("1", "9")):
+        monkeypatch.setenv("BZ_GATE", gate)
+        monkeypatch.setenv("BZ_TEST_GATE_TIMEOUT", sab)
+        monkeypatch.setenv("BZ_GATE_SPIN", "20000")
+        prob = bz.Problem(*dev, n, n, np.float64)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), x0)
+        prob.panoc_steps(40)
+        st = prob.panoc_stats()
+        runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(), st))
+        # the gate stays off for later solves on this problem
+        monkeypatch.setenv("BZ_TEST_GATE_TIMEOUT", "0")
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), x0)
+        prob.panoc_steps(10)
+        runs[-1] += (prob.panoc_stats(),)
+        prob.close()
+    a, b = runs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for key in ("k", "gamma", "f_x", "stop_norm", "FBE"):
+        assert a[2][key] == b[2][key], key
+    assert a[3].n_gate_fallbacks == 0 and b[3].n_gate_fallbacks == 1
+    assert 1 <= b[3].n_gated_launches <= 10 and a[3].n_grad == b[3].n_grad
+    assert b[4].n_gated_launches == 0

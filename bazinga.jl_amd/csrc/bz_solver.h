@@ -110,8 +110,8 @@ constexpr int CM = 5;            // capacity of the compact L-BFGS form (pairs)
 template <class T>
 using FusedFn = void (*)(CompactVecs<T, CM>, CompactCoef<CM>, const T*, const T*, ElemParams<T>, T, T*, T*, T*, T*, T*,
                          int64_t, double*, int);
-template <class T, int DK> FusedFn<T> family_kernel_dk(int fam, bool nt);      // bz_families_dk<DK>.hip
-template <class T> FusedFn<T> family_kernel(int fam, bool nt);
+template <class T, int DK> FusedFn<T> family_kernel_dk(int fam, bool nt, int uni);      // bz_families_dk<DK>.hip
+template <class T> FusedFn<T> family_kernel(int fam, bool nt, int uni = -1);
 
 struct SolverBase {
     virtual ~SolverBase() = default;

@@ -1015,9 +1015,14 @@ template <class T> class Solver final : public SolverBase {
         const T gam = (T)pl.gamma;
         if (pl.table) {
             C2.uni_rt = pl.uni; C2.trial_rt = 0;
-            FusedFn<T> fn = family_kernel<T>(pl.fam, pl.nt);
+            // the plain pass with uniform penalties has compile-time instantiations (fp64); run-time UNI / TRIAL otherwise
+            static const int famct_env = std::getenv("BZ_FAMCT") ? std::atoi(std::getenv("BZ_FAMCT")) : 1;
+            FusedFn<T> fn = (famct_env && !famrt_env_) ? family_kernel<T>(pl.fam, pl.nt, pl.uni) : nullptr;
+            const bool ct = fn != nullptr;
+            if (!fn) fn = family_kernel<T>(pl.fam, pl.nt, -1);
             if (!fn) throw Error(BZ_ERR_STATE, "no one-pass kernel instantiation for this oracle family");
-            form_[C_FUSED_IT] = "k_fused_compact<XR=2,UNI=-1,NT=" + std::to_string(pl.nt ? 1 : 0) + ",TRIAL=-1,FAM=" + std::to_string(pl.fam) + ">";
+            form_[C_FUSED_IT] = std::string("k_fused_compact<XR=2,UNI=") + (ct ? std::to_string(pl.uni) : std::string("-1")) + ",NT=" +
+                                std::to_string(pl.nt ? 1 : 0) + ",TRIAL=" + (ct ? "0" : "-1") + ",FAM=" + std::to_string(pl.fam) + ">";
             launch(C_FUSED_IT, fn, pl.gfc, XV, C2, pl.x, (const T*)nullptr, P, gam, pl.xd, zarg, (T*)nullptr, (T*)nullptr,
                    (T*)nullptr, n, parts_.p, (int)SL_TRIAL);
         } else {
@@ -2815,16 +2820,16 @@ template <class T> class Solver final : public SolverBase {
 
 // one-pass kernel of an oracle family: the instantiations live in bz_families_dk*.hip (one file per D class, so that
 // they compile in parallel)
-template <class T> FusedFn<T> family_kernel(int fam, bool nt) {
+template <class T> FusedFn<T> family_kernel(int fam, bool nt, int uni) {
     switch (fam_dk(fam)) {
-    case FAM_D_ZERO: return family_kernel_dk<T, FAM_D_ZERO>(fam, nt);
-    case FAM_D_FREE: return family_kernel_dk<T, FAM_D_FREE>(fam, nt);
-    case FAM_D_BOX: return family_kernel_dk<T, FAM_D_BOX>(fam, nt);
-    case FAM_D_BOX_VEC: return family_kernel_dk<T, FAM_D_BOX_VEC>(fam, nt);
-    case FAM_D_VC: return family_kernel_dk<T, FAM_D_VC>(fam, nt);
-    case FAM_D_CC: return family_kernel_dk<T, FAM_D_CC>(fam, nt);
-    case FAM_D_EITHEROR: return family_kernel_dk<T, FAM_D_EITHEROR>(fam, nt);
-    case FAM_D_XOR: return family_kernel_dk<T, FAM_D_XOR>(fam, nt);
+    case FAM_D_ZERO: return family_kernel_dk<T, FAM_D_ZERO>(fam, nt, uni);
+    case FAM_D_FREE: return family_kernel_dk<T, FAM_D_FREE>(fam, nt, uni);
+    case FAM_D_BOX: return family_kernel_dk<T, FAM_D_BOX>(fam, nt, uni);
+    case FAM_D_BOX_VEC: return family_kernel_dk<T, FAM_D_BOX_VEC>(fam, nt, uni);
+    case FAM_D_VC: return family_kernel_dk<T, FAM_D_VC>(fam, nt, uni);
+    case FAM_D_CC: return family_kernel_dk<T, FAM_D_CC>(fam, nt, uni);
+    case FAM_D_EITHEROR: return family_kernel_dk<T, FAM_D_EITHEROR>(fam, nt, uni);
+    case FAM_D_XOR: return family_kernel_dk<T, FAM_D_XOR>(fam, nt, uni);
     default: return nullptr;
     }
 }

@@ -56,7 +56,10 @@ def form_of(kernel):
         fam = a[8] if len(a) > 8 else "35"
         if xr == "2":
             s = f"k_fused_compact<XR=2,UNI={uni},NT={int(nt)},TRIAL={trial}"
-            return s + (f",FAM={fam}>" if uni == "-1" else ">")      # (the headline family's own instantiations carry no FAM tag)
+            # (the headline family's own instantiations carry no FAM tag: they are the ones with the default FAM = 35 and a
+            # compile-time UNI that the host launches outside the family table)
+            table = uni == "-1" or (len(a) > 8 and fam != "35")
+            return s + (f",FAM={fam}>" if table else ">")
         if xr == "1":
             return f"k_fused_compact<XR=1,NT={int(nt)}>"
         return f"k_fused_compact<XR=0,SPEC={int(spec)},NT={int(nt)}>"

@@ -39,6 +39,7 @@ class CtxOpts(C.Structure):
 
 
 BZ_CTX_RUNTIME_TUNING = 1
+BZ_CTX_SHARED_DEVICE = 2
 
 
 class ProfileRec(C.Structure):

@@ -79,7 +79,7 @@ int bz_ctx_create(const bz_ctx_opts* o, bz_ctx** out) {
         need(o, "opts"); need(out, "out");
         if (o->nranks < 1 || o->rank < 0 || o->rank >= o->nranks)
             throw bz::Error(BZ_ERR_ARG, "rank/nranks out of range");
-        if (o->flags & ~BZ_CTX_RUNTIME_TUNING) throw bz::Error(BZ_ERR_ARG, "unknown bz_ctx_opts.flags bit");
+        if (o->flags & ~(BZ_CTX_RUNTIME_TUNING | BZ_CTX_SHARED_DEVICE)) throw bz::Error(BZ_ERR_ARG, "unknown bz_ctx_opts.flags bit");
         if (o->flags & BZ_CTX_RUNTIME_TUNING) (void)apply_runtime_tuning();      // before the first HIP call below
         int ndev = 0;
         BZ_HIP(hipGetDeviceCount(&ndev));
@@ -88,6 +88,7 @@ int bz_ctx_create(const bz_ctx_opts* o, bz_ctx** out) {
         auto* c = new bz_ctx();
         try {
             c->c.device = o->device; c->c.rank = o->rank; c->c.nranks = o->nranks;
+            c->c.shared_device = (o->flags & BZ_CTX_SHARED_DEVICE) != 0;
             BZ_HIP(hipSetDevice(o->device));
             BZ_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
             // nranks == 1 with a comm_id builds a 1-rank communicator: exercises the all-gather

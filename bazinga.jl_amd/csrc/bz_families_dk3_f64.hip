@@ -1,0 +1,4 @@
+// one-pass iteration kernels of the oracle families with D class 3 (FAM_D_*, bz_kernels.h), double
+#define BZ_FAMILY_DK 3
+#define BZ_FAMILY_T double
+#include "bz_families.inc"

@@ -16,11 +16,13 @@ class Context:
     """One per process/GPU (bz_ctx).  nranks > 1: x is sharded over the ranks and the
     reductions' partial scalars are all-gathered with RCCL."""
 
-    def __init__(self, device=0, rank=0, nranks=1, comm_id: bytes | None = None, runtime_tuning: bool = False):
+    def __init__(self, device=0, rank=0, nranks=1, comm_id: bytes | None = None, runtime_tuning: bool = False,
+                 shared_device: bool = False):
         lib = L.load()
         o = L.CtxOpts()
         o.device, o.rank, o.nranks = device, rank, nranks
-        o.flags = L.BZ_CTX_RUNTIME_TUNING if runtime_tuning else 0
+        # shared_device: the GPU is not this process's own — no launch is made to wait, resident, at a gate
+        o.flags = (L.BZ_CTX_RUNTIME_TUNING if runtime_tuning else 0) | (L.BZ_CTX_SHARED_DEVICE if shared_device else 0)
         self._id = None
         if comm_id is not None and len(comm_id) != 128:
             raise ValueError("comm_id must be the 128-byte id from unique_id() on rank 0")

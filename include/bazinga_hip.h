@@ -115,6 +115,11 @@ typedef struct {
 
 /* bz_ctx_opts.flags */
 #define BZ_CTX_RUNTIME_TUNING 1   /* apply bz_runtime_tuning() before this context's first HIP call         */
+#define BZ_CTX_SHARED_DEVICE  2   /* the GPU is not this process's own (other processes, other HIP users in this one): no
+                                     launch is ever made to wait, resident, at a gate — a polling launch holds its CUs, and
+                                     tenants that do that starve each other ("Who decides at the gate").  Costs the
+                                     ~6 us per iteration the gated pre-launch saves.  Implied between ranks that
+                                     bz_ctx_p2p_connect finds on one device.                                            */
 
 /* ROCm runtime settings for a launch-latency-bound host loop (one short kernel chain per PANOC iteration with
  * the host in the loop): HIP_FORCE_DEV_KERNARG=1 (kernel arguments in device memory) and HSA_ENABLE_INTERRUPT=0

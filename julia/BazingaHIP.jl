@@ -19,7 +19,7 @@ const lib = get(ENV, "BAZINGA_HIP_LIB", "libbazinga_hip.so")
 
 # ---- mirrors of the C structs (include/bazinga_hip.h) ----------------------------------------
 struct CtxOpts
-    device::Int32; rank::Int32; nranks::Int32; flags::Int32; comm_id::Ptr{Cvoid}      # flags: BZ_CTX_RUNTIME_TUNING = 1
+    device::Int32; rank::Int32; nranks::Int32; flags::Int32; comm_id::Ptr{Cvoid}      # flags: BZ_CTX_RUNTIME_TUNING = 1, BZ_CTX_SHARED_DEVICE = 2
 end
 Base.@kwdef mutable struct ProblemDesc
     dtype::Int32 = 0; f_kind::Int32 = 0; g_kind::Int32 = 0; c_kind::Int32 = 0; D_kind::Int32 = 0

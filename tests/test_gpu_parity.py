@@ -1476,6 +1476,24 @@ def test_gated_prelaunch_is_bitwise_neutral(bz, ref, fam, monkeypatch):
     assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3] and np.array_equal(outs[0][0], outs[1][0])
 
 
+def test_shared_device_context_does_not_gate(bz, ref):
+    """BZ_CTX_SHARED_DEVICE: the host says the GPU is not its own — the library's loop makes plain launches only"""
+    n = 200_003
+    d, dev, orc = make_cfg2(bz, ref, n)
+    outs = []
+    for shared in (False, True):
+        ctx = bz.Context(device=0, shared_device=shared)
+        prob = bz.Problem(*dev, n, n, np.float64, ctx)
+        prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), np.zeros(n))
+        prob.panoc_steps(30)
+        outs.append((prob.panoc_vector("x"), prob.panoc_stats()))
+        prob.close()
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1].n_gated_launches >= 20 and outs[1][1].n_gated_launches == 0
+
+
 def test_gate_timeout_falls_back_to_plain_launches(bz, ref, monkeypatch):
     """A pre-launched pass that is not released in time (a stalled host thread; another tenant on the GPU keeping its
     first workgroup from becoming resident) leaves as a whole, the host redoes the iteration with a plain launch and keeps

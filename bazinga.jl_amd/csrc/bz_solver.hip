@@ -2491,10 +2491,12 @@ template <class T> class Solver final : public SolverBase {
             if (!res_valid) ensure_z();
             // x_d = x + d ; gradient at x_d ; state.x = x_d
             if (use_compact) {
-                mv(2 * CV.m + 3); nm("k_compact_xd");
+                mv(2 * CV.m + 3);
                 // (full memory + a history beyond the Infinity Cache: compile-time trip counts, non-temporal history loads)
                 static const int xdnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
                 const bool hist_nt = xdnt_env && (double)n * sizeof(T) * (2 * CV.m + 3) > 340e6;
+                // (the template form in the name: a hardware-counter profile is matched to the instantiation that ran)
+                nm(CV.m == CM ? (hist_nt ? "k_compact_xd<FULL=1,NT=1>" : "k_compact_xd<FULL=1,NT=0>") : "k_compact_xd<FULL=0,NT=0>");
                 if (CV.m == CM && hist_nt)
                     launch(C_XD, k_compact_xd<T, CM, true, true>, grid, CV, CC, (const T*)RES_[rp].p, (const T*)X_[xp].p, X_[xd].p, n);
                 else if (CV.m == CM)
@@ -2514,9 +2516,9 @@ template <class T> class Solver final : public SolverBase {
                 // (uniform penalties / zero multipliers travel as numbers, P.uni: the two stencil passes stream mu and mu*y
                 // otherwise — 4 of the iteration's 43 passes)
                 mv(2 + pstreams(false, true, true) + 3);        // x_d, b + parameters ; grad, z, res
-                nm("k_stencil_fb");
                 const StencilHalo<T> halo_x = halo_exchange(X_[xd].p);
                 static const int fbnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
+                nm(fbnt_env && (double)n * sizeof(T) * 12 > 340e6 ? "k_stencil_fb<NT=1>" : "k_stencil_fb<NT=0>");
                 if (fbnt_env && (double)n * sizeof(T) * 12 > 340e6)
                     launch(C_STENCIL_FB, k_stencil_fb<T, true>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
                            (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
@@ -2530,7 +2532,6 @@ template <class T> class Solver final : public SolverBase {
                     // ... with the Gram products of the new pair and the next application's p, w in the same pass
                     for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
                     mv(2 + pstreams(false, true, false) + 5 + 2 + 2 * CV.m);
-                    nm("k_stencil_update_c");
 #define BZ_LAUNCH_SUC(FULL_, NT_)                                                                                 \
     launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
            (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p, (const T*)RES_[rp].p, \
@@ -2538,6 +2539,8 @@ template <class T> class Solver final : public SolverBase {
                     {
                         static const int xdnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
                         const bool hist_nt = xdnt_env && (double)n * sizeof(T) * (2 * CV.m + 12) > 340e6;
+                        nm(CV.m == CM ? (hist_nt ? "k_stencil_update_c<FULL=1,NT=1>" : "k_stencil_update_c<FULL=1,NT=0>")
+                                      : "k_stencil_update_c<FULL=0,NT=0>");
                         if (CV.m == CM && hist_nt) BZ_LAUNCH_SUC(true, true);
                         else if (CV.m == CM) BZ_LAUNCH_SUC(true, false);
                         else BZ_LAUNCH_SUC(false, false);

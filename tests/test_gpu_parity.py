@@ -458,8 +458,8 @@ def test_stencil_compact_form_is_the_default_and_runs_without_the_persistent_ker
     p = prob.profile2()
     prob.close()
     assert p["k_twoloop_persist"]["launches"] == 0 and p["k_axpy_dot"]["launches"] == 0
-    assert p["k_stencil_update"]["form"] == "k_stencil_update_c" and p["k_stencil_update"]["launches"] >= 11
-    assert p["x_d"]["form"] == "k_compact_xd"
+    assert p["k_stencil_update"]["form"].startswith("k_stencil_update_c<") and p["k_stencil_update"]["launches"] >= 11
+    assert p["x_d"]["form"].startswith("k_compact_xd<")
 
 
 def test_stencil_alps_small_obstacle(bz, ref):

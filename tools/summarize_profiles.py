@@ -63,6 +63,12 @@ def form_of(kernel):
         if xr == "1":
             return f"k_fused_compact<XR=1,NT={int(nt)}>"
         return f"k_fused_compact<XR=0,SPEC={int(spec)},NT={int(nt)}>"
+    m = re.match(r"(k_compact_xd|k_stencil_update_c)<\w+, \d+(?:, (true|false), (true|false))?>$", k)
+    if m:
+        return f"{m.group(1)}<FULL={int(m.group(2) == 'true')},NT={int(m.group(3) == 'true')}>"
+    m = re.match(r"k_stencil_fb<\w+(?:, (true|false))?>$", k)
+    if m:
+        return f"k_stencil_fb<NT={int(m.group(1) == 'true')}>"
     m = re.match(r"k_twoloop_persist<\w+, (\d+)>$", k)
     if m:
         return f"k_twoloop_persist<KR={m.group(1)}>"

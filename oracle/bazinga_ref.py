@@ -1402,8 +1402,8 @@ class NonsmoothCostFunSlack:
 def als(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol=None, maxit=100,
         theta_penalty=0.8, kappa_penalty=0.5, kappa_tol=0.1, verbose=False,
         dual_safeguard=default_dual_safeguard, subsolver=default_subsolver,
-        subsolver_maxit=1_000_000_000):
-    """als.jl:7-120.  Same 10-tuple as alps."""
+        subsolver_maxit=1_000_000_000, warm_start=False):
+    """als.jl:7-120.  Same 10-tuple as alps.  warm_start: as in `alps` (not in the reference; bit 0 only)."""
     start_time = time.time()
     T = x0.dtype.type
     nx, ny = x0.shape[0], y0.shape[0]
@@ -1438,7 +1438,10 @@ def als(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_tol
     while not can_stop:
         tot_it += 1
         dual_safeguard(y, cx)                                  # :66
-        sub_solver = subsolver(tol=inner_tol, verbose=verbose)
+        if warm_start and tot_it > 1 and getattr(sub_solver, "last_state", None) is not None:
+            sub_solver = subsolver(tol=inner_tol, verbose=verbose, gamma=sub_solver.last_state.gamma, adaptive=True)
+        else:
+            sub_solver = subsolver(tol=inner_tol, verbose=verbose)
         AugLagUpdateSlack(fSlack, mu, y)                       # :69
         xSlack[:nx] = x
         xSlack[nx:] = s

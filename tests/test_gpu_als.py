@@ -85,6 +85,22 @@ def test_als_matches_oracle_and_alps(bz, ref, resident):
     assert not np.any(x0)
 
 
+def test_als_warm_start_matches_the_warm_started_oracle(bz, ref):
+    """als(warm_start=True) (bz_alps_opts.warm_start through bz_als_solve): the step size carried across subproblems, as
+    in alps — the resident loop against the oracle restated with the same option; the host loop refuses it."""
+    n = 3000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    a = bz.als(*dev, x0, y0, resident=True, warm_start=True)
+    o = ref.als(*orc, x0, y0, warm_start=True)
+    cold = ref.als(*orc, x0, y0)
+    assert a[5] == o[5] == "first_order" and a[2] == o[2]
+    assert abs(a[3] - o[3]) <= max(3, 0.03 * o[3])
+    assert rel(a[0], o[0]) <= 1e-7 and rel(a[0], cold[0]) <= 1e-4
+    with pytest.raises(bz.UnsupportedOracle):
+        bz.als(*dev, x0, y0, resident=False, warm_start=True)
+
+
 def test_als_rejects_unsupported(bz, ref):
     n = 64
     d = bz.synth.obstacle_grid(8, 8)

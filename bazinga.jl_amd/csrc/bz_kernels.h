@@ -2088,17 +2088,8 @@ template <int MM> struct CompactCoef {
     GateRec* gate_dev;
     int* gate_timeout;
     int gate_other_stream;     // launched on another stream than the pass before it (may be resident while that one runs)
-    int keepx;                 // experiment (BZ_KEEPX): x_d is stored and x loaded with the default cache policy while every
-                               // other stream stays non-temporal, so that the iterate written by one pass may be served from
-                               // the Infinity Cache to the next
-    // read-back folded into the gated launch (fold_n != 0): before it goes to its gate, the first wave of workgroup i folds
-    // scalar i of the PREVIOUS pass (exchanges it with the other ranks' through the mailboxes, if any) and posts it to the
-    // host — the work of k_collect_w / k_exchange_collect without their launch: one kernel boundary and one small
-    // kernel's ramp less between two passes
     unsigned gate_spin_host, gate_spin_dev;      // poll bounds of workgroup 0 (host record) and of the others (device flag)
-    int fold_n;
     int gate_late;             // the pipelined form goes to its gate AFTER issuing the loads of its first packs
-    XCollectArgs fold;
 };
 
 // K1: p_i = <s_i, -res>, w_i = <y_i, -res>   slots: slot0 + i (p), slot0 + MM + i (w)
@@ -2515,12 +2506,6 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
     T H0 = (T)C.H0;
     T gl = gamma * P.g_lambda;
     __shared__ unsigned long long gate_sh;
-    // the previous pass's read-back, folded into this launch (one wave per scalar, spread over the workgroups): first
-    // thing in the kernel — the host's turn-around starts when these scalars arrive
-    if constexpr (XR == 2) {
-        if (C.gate_seq != 0ull && C.fold_n && threadIdx.x < 64)
-            for (int i = (int)blockIdx.x; i < C.fold_n; i += (int)gridDim.x) exchange_collect_one(C.fold, i, (int)threadIdx.x);
-    }
     // the gate of a pre-launched pass (see GateRec); returns false when the host recalled the launch
     auto gate_wait = [&]() -> bool {
         if constexpr (XR == 2) {
@@ -2614,7 +2599,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
         if (fk == BZ_F_DIAG_QUADRATIC) { S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo); }
         if (uni < 1) S.mu = ldo<T, NT>(P.mu, bo);
         if (uni < 2) S.muy = ldo<T, NT>(P.muy, bo);
-        if (NT && (C.keepx & 2)) S.px = ldo<T, false>(x, bo); else S.px = ldo<T, NT>(x, bo);
+        S.px = ldo<T, NT>(x, bo);
         if (trial) S.xt = ldo<T, NT>((const T*)x_d, bo);
 #pragma unroll
         for (int i = 0; i < MM; ++i) S.ps[i] = ldo<T, NT>(V.S[i], bo);
@@ -2785,7 +2770,7 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
             }
         }
         if constexpr (O32) {
-            if (!trial) { if (NT && (C.keepx & 1)) sto<T, false>(x_d, bo, pxd); else sto<T, NT>(x_d, bo, pxd); }
+            if (!trial) sto<T, NT>(x_d, bo, pxd);
             if (z) sto<T, NT>(z, bo, pz);
             if (XR != 2 || res) sto<T, NT>(res, bo, pr);
             if constexpr (XR == 0) { sto<T, NT>(s_new, bo, pss); sto<T, NT>(y_new, bo, pyy); }

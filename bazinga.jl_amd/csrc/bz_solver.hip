@@ -1010,8 +1010,6 @@ template <class T> class Solver final : public SolverBase {
         XV.m = CM;
         for (int i = 0; i < CM; ++i) { XV.S[i] = pl.S[i]; XV.Y[i] = nullptr; }
         C2.gam0 = pl.gam0;
-        static const int keepx_env = std::getenv("BZ_KEEPX") ? std::atoi(std::getenv("BZ_KEEPX")) : 0;
-        C2.keepx = keepx_env;
         const T gam = (T)pl.gamma;
         if (pl.table) {
             C2.uni_rt = pl.uni; C2.trial_rt = 0;
@@ -1036,12 +1034,10 @@ template <class T> class Solver final : public SolverBase {
         }
     }
     // launch the NEXT iteration's pass now, gated on the host record
-    // (fold: the read-back of the CURRENT pass's scalars rides in the early launch, see CompactCoef::fold)
-    void gate_prelaunch(const GatePlan& pl, const XCollectArgs* fold = nullptr, int fold_n = 0) {
+    void gate_prelaunch(const GatePlan& pl) {
         gate_alloc();
         CompactCoef<CM> C2;
         std::memset(&C2, 0, sizeof(C2));
-        if (fold) { C2.fold = *fold; C2.fold_n = fold_n; }
         static const int glate_env = std::getenv("BZ_GATELATE") ? std::atoi(std::getenv("BZ_GATELATE")) : 1;
         C2.gate_late = glate_env;
         // (BZ_GATE_SPIN: the poll bounds, for the test of the fall-back)
@@ -2450,29 +2446,18 @@ template <class T> class Solver final : public SolverBase {
                 gr[xd] = (double)gamma;
                 have_plan = gate_make_plan(xd, std::min(m_now + 1, M), gr, xr_run_ + 1, nxt);
             }
-            // (BZ_GATEFOLD=1, off by default: measured no gain — the fold inside a 256-workgroup launch takes as long as the
-            // small read-back kernel and its boundary did: 29.5-31 us per iteration at n = 1.25e6 either way, NEXT.md)
-            static const int gfold_env = std::getenv("BZ_GATEFOLD") ? std::atoi(std::getenv("BZ_GATEFOLD")) : 0;
-            if (have_plan && gfold_env && gate_env_ == 1 && (!ctx->multi() || ctx->p2p_on)) {
-                // ... and this pass's read-back (with its exchange over the ranks) rides in that launch: no k_collect_w /
-                // k_exchange_collect kernel between the two passes
-                const XCollectArgs fold = make_xcollect(SL_TRIAL, NFC, 1u << 9);
-                tail_ticket = fold.ticket; tail_used = true;
-                gate_prelaunch(nxt, &fold, NFC);
+            if (ctx->p2p_on) {
+                // exchange + fold over the ranks + read-back in one launch (no k_collect)
+                tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
+                tail_used = true;
             } else {
-                if (ctx->p2p_on) {
-                    // exchange + fold over the ranks + read-back in one launch (no k_collect)
-                    tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
+                gather(SL_TRIAL, NFC, 1u << 9);
+                if (xr == 2 && gate_env_) {      // the read-back kernel now, so that the next pass can queue right behind it
+                    tail_ticket = collect_launch_range(SL_TRIAL, NFC, 1u << 9);
                     tail_used = true;
-                } else {
-                    gather(SL_TRIAL, NFC, 1u << 9);
-                    if (xr == 2 && gate_env_) {      // the read-back kernel now, so that the next pass can queue right behind it
-                        tail_ticket = collect_launch_range(SL_TRIAL, NFC, 1u << 9);
-                        tail_used = true;
-                    }
                 }
-                if (have_plan) gate_prelaunch(nxt);
             }
+            if (have_plan) gate_prelaunch(nxt);
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
             n_grad += 2; n_prox += 1;
         } else if (fused_ok) {

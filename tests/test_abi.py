@@ -112,3 +112,38 @@ def test_product_does_not_import_the_oracle():
     code = "import sys; sys.path.insert(0, %r); import bazinga_jl_amd; " \
            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % ROOT
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_julia_shim_structs_mirror_the_ctypes_twin(bz):
+    """julia/BazingaHIP.jl cannot be executed here (no Julia): at least its struct mirrors are compared, field by field —
+    name, order and width — with the ctypes structs that test_struct_layouts_match_the_header pins to the C header, and
+    the defaults its keyword constructors give PanocOpts / AlpsOpts with what bz_*_default_opts fill in."""
+    import re
+    L = bz._lib
+    src = open(os.path.join(ROOT, "julia", "BazingaHIP.jl")).read()
+    width = {"Int32": 4, "Int64": 8, "Float64": 8, "Ptr{Cvoid}": 8, "UInt64": 8}
+    ctw = {C.c_int32: 4, C.c_int64: 8, C.c_double: 8, C.c_void_p: 8}
+    twins = {"CtxOpts": L.CtxOpts, "ProblemDesc": L.ProblemDesc, "PanocOpts": L.PanocOpts, "PanocStats": L.PanocStats,
+             "AlpsOpts": L.AlpsOpts, "AlpsStats": L.AlpsStats}
+    parsed = {}
+    for name, ct in twins.items():
+        m = re.search(r"(?:mutable )?struct " + name + r"\n(.*?)\nend", src, re.S)
+        assert m, f"struct {name} not found in the Julia shim"
+        body = re.sub(r"#.*", "", m.group(1))
+        fields = re.findall(r"(\w+)::([\w{}]+)(?:\s*=\s*([^;\n]+))?", body)
+        parsed[name] = fields
+        jl = [(f, width[t]) for f, t, _ in fields]
+        cf = []
+        for fname, ftype in ct._fields_:
+            cf.append((fname, ctw[ftype] if ftype in ctw else C.sizeof(ftype)))
+        assert jl == cf, f"{name}: Julia {jl} vs ctypes {cf}"
+    o = L.PanocOpts()
+    L.load().bz_panoc_default_opts(C.byref(o))
+    for f, t, dflt in parsed["PanocOpts"]:
+        assert dflt is not None and float(eval(dflt.strip().replace("_", ""))) == float(getattr(o, f)), f"PanocOpts.{f}: {dflt}"
+    a = L.AlpsOpts()
+    L.load().bz_alps_default_opts(C.byref(a), L.BZ_F64)
+    for f, t, dflt in parsed["AlpsOpts"]:
+        want = float(getattr(a, f))
+        got = float(eval(dflt.strip().replace("_", "").replace("cbrt(1e-6)", "1e-6 ** (1 / 3)")))
+        assert abs(got - want) <= 1e-15 * max(1.0, abs(want)), f"AlpsOpts.{f}: {dflt} vs {want}"

@@ -147,3 +147,40 @@ def test_julia_shim_structs_mirror_the_ctypes_twin(bz):
         want = float(getattr(a, f))
         got = float(eval(dflt.strip().replace("_", "").replace("cbrt(1e-6)", "1e-6 ** (1 / 3)")))
         assert abs(got - want) <= 1e-15 * max(1.0, abs(want)), f"AlpsOpts.{f}: {dflt} vs {want}"
+
+
+def test_julia_shim_ccalls_match_the_exported_signatures(bz):
+    """... and every `ccall` of the shim names an exported entry point with as many arguments as the ctypes twin passes,
+    pointers where it passes pointers."""
+    import re
+    L = bz._lib
+    src = open(os.path.join(ROOT, "julia", "BazingaHIP.jl")).read()
+    src = re.sub(r"#.*", "", src)
+    calls = re.findall(r"ccall\(\(:(\w+), lib\),\s*(\w+),\s*\((.*?)\)\s*[,)]", src, re.S)
+    assert len(calls) >= 7
+    lib = L.load()
+    for name, ret, types in calls:
+        assert name in L.SIGNATURES, f"{name} is not an entry point of the library"
+        assert hasattr(lib, name)
+        res, args = L.SIGNATURES[name]
+        depth, parts, cur = 0, [], ""
+        for ch in types:                                   # split on top-level commas (Ref{Ptr{Cvoid}} holds none, but be safe)
+            if ch == "{":
+                depth += 1
+            elif ch == "}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                parts.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append(cur.strip())
+        assert len(parts) == len(args), f"{name}: Julia passes {parts}, the library takes {len(args)} arguments"
+        for jt, ct in zip(parts, args):
+            is_ptr_j = jt.startswith(("Ptr{", "Ref{")) or jt == "Cstring"
+            is_ptr_c = ct in (C.c_void_p, C.c_char_p) or hasattr(ct, "contents")
+            assert is_ptr_j == is_ptr_c, f"{name}: {jt} vs {ct}"
+            if not is_ptr_j:
+                assert {"Cint": 4, "Int32": 4, "Int64": 8, "Cdouble": 8, "Float64": 8}[jt] == C.sizeof(ct), f"{name}: {jt} vs {ct}"
+        assert (ret == "Cvoid") == (res is None) and (ret == "Cstring") == (res is C.c_char_p)

@@ -177,7 +177,7 @@ void bz_panoc_default_opts(bz_panoc_opts* o) {
     o->tol = 1e-8; o->maxit = 1000; o->freq = 10; o->verbose = 0;
     o->minimum_gamma = 1e-7; o->alpha = 0.95; o->beta = 0.5;
     o->max_backtracks = 20; o->lbfgs_memory = 5; o->fuse = 1; o->persist = 1; o->lbfgs_compact = 2;
-    o->affine_refresh = 8; o->directions = BZ_DIR_LBFGS; o->broyden_theta_bar = 0.2;
+    o->affine_refresh = 16; o->directions = BZ_DIR_LBFGS; o->broyden_theta_bar = 0.2;
     o->gamma = 0.0; o->Lf = 0.0; o->adaptive = -1; o->reserved2 = 0;
 }
 

@@ -166,7 +166,7 @@ class PANOCplus:
 
     def __init__(self, *, directions=None, maxit=1000, tol=1e-8, verbose=False, freq=10,
                  minimum_gamma=1e-7, alpha=0.95, beta=0.5, max_backtracks=20, fuse=True, persist=True,
-                 affine_refresh=8, ctx=None, Lf=None, gamma=None, adaptive=None):
+                 affine_refresh=16, ctx=None, Lf=None, gamma=None, adaptive=None):
         self.directions = directions if directions is not None else LBFGS(5)
         if not isinstance(self.directions, (LBFGS, NoAcceleration, AndersonAcceleration, Broyden)):
             raise UnsupportedOracle("directions must be LBFGS(M), NoAcceleration(), AndersonAcceleration(n) or Broyden()")

@@ -39,7 +39,7 @@ Base.@kwdef mutable struct PanocOpts
     tol::Float64 = 1e-8; maxit::Int64 = 1000; freq::Int32 = 10; verbose::Int32 = 0
     minimum_gamma::Float64 = 1e-7; alpha::Float64 = 0.95; beta::Float64 = 0.5
     max_backtracks::Int32 = 20; lbfgs_memory::Int32 = 5; fuse::Int32 = 1; persist::Int32 = 1
-    lbfgs_compact::Int32 = 2; affine_refresh::Int32 = 8
+    lbfgs_compact::Int32 = 2; affine_refresh::Int32 = 16
     directions::Int32 = 0; reserved::Int32 = 0; broyden_theta_bar::Float64 = 0.2      # BZ_DIR_LBFGS / _ANDERSON (1) / _BROYDEN (2)
     gamma::Float64 = 0; Lf::Float64 = 0; adaptive::Int32 = -1; reserved2::Int32 = 0  # 0 = nothing; adaptive -1 = (gamma === nothing)
 end
@@ -230,7 +230,7 @@ function PANOCplus(; directions = nothing, maxit = 1000, tol = 1e-8, verbose = f
     PANOCplusHIP(PanocOpts(tol = tol, maxit = min(maxit, typemax(Int64)), freq = min(freq, typemax(Int32)),
                            verbose = verbose, minimum_gamma = minimum_gamma, alpha = alpha, beta = beta,
                            max_backtracks = max_backtracks, lbfgs_memory = M, lbfgs_compact = compact,
-                           affine_refresh = get(kwargs, :affine_refresh, 8),
+                           affine_refresh = get(kwargs, :affine_refresh, 16),
                            gamma = gamma === nothing ? 0.0 : gamma, Lf = Lf === nothing ? 0.0 : Lf, adaptive = Int32(adaptive)))
 end
 

@@ -446,8 +446,10 @@ def test_row_sharded_dense_constraint_alps(bz):
     assert all(r[3][2] == o[5] == "first_order" for r in res)
     # ~2000 inner iterations of a nonsmooth problem with tau backtracks: the two runs follow each other for the
     # first ~70 iterations (the 1e-10 test above) and then take different, equally valid paths to the same
-    # solution — counts agree loosely, the solutions to the solver's tolerance
-    assert all(abs(r[3][0] - o[2]) <= 3 and abs(r[3][1] - o[3]) <= 0.25 * o[3] for r in res)
+    # solution — counts agree loosely, the solutions to the solver's tolerance.  (How loosely: the same problem solved
+    # with affine_refresh = 0, 1, 4, 8, 16, 32, 64 — seven roundings of one algorithm — takes 11, 10, 14, 11, 13, 12, 9 outer
+    # and 2278 ... 2729 inner iterations, tools/refresh_counts.py.)
+    assert all(abs(r[3][0] - o[2]) <= 5 and abs(r[3][1] - o[3]) <= 0.25 * o[3] for r in res)
     assert np.max(np.abs(res[0][1] - o[0])) <= 5e-4 * max(1.0, np.max(np.abs(o[0])))
     assert np.array_equal(np.abs(res[0][1]) > 1e-3, np.abs(o[0]) > 1e-3)          # same support
     assert np.max(np.abs(A @ res[0][1] - b)) <= 1e-5

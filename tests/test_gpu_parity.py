@@ -133,7 +133,7 @@ def _err(a, b):
 
 
 def run_traces(bz, ref, dev, orc, n, mu, y, x0, iters, fuse=True, minimum_gamma=1e-7, dtype=np.float64,
-               ny=None, compact=None, affine_refresh=8):
+               ny=None, compact=None, affine_refresh=16):
     """Step the device solver and the oracle side by side.  Returns rows
     (k, err_x, err_z, gamma_dev, gamma_ref, stop_dev, stop_ref, fused, self_sensitivity)."""
     ny = n if ny is None else ny

@@ -195,3 +195,30 @@ int main(void) {
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert int(out[0]) == 40_080_000 and int(out[1]) == 0
+
+
+def test_profile_forms_are_reproducible_from_kernel_names():
+    """bench.py attaches PMC traffic to a roofline object by the template FORM the library reports; the summariser derives
+    that form from rocprof's kernel names.  Every committed entry must be the image of its own kernel name, the forms of
+    one workload must be distinct per instantiation, and the entries must belong to one build of the kernel sources."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import summarize_profiles as sp
+    d = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert len(d["entries"]) > 30
+    seen = {}
+    for e in d["entries"]:
+        assert sp.form_of(e["kernel"]) == e["form"], e
+        key = (e["workload"], e["n"], e["form"])
+        assert key not in seen or seen[key] == e["kernel"], f"two instantiations share the form {key}"
+        seen[key] = e["kernel"]
+    assert len({e["lib_sources_sha"] for e in d["entries"]}) == 1
+    # the instantiations the solver names explicitly
+    assert sp.form_of("bz::k_stencil_update_c<double, 5, true, true>") == "k_stencil_update_c<FULL=1,NT=1>"
+    assert sp.form_of("bz::k_compact_xd<float, 5, true, false>") == "k_compact_xd<FULL=1,NT=0>"
+    assert sp.form_of("bz::k_stencil_fb<double, true>") == "k_stencil_fb<NT=1>"
+    assert sp.form_of("bz::k_fused_compact<double, 5, true, true, true, 2, 2, 0, 39>") == "k_fused_compact<XR=2,UNI=2,NT=1,TRIAL=0,FAM=39>"
+    assert sp.form_of("bz::k_fused_compact<double, 5, true, true, true, 2, 2, 0, 35>") == "k_fused_compact<XR=2,UNI=2,NT=1,TRIAL=0>"

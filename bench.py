@@ -683,14 +683,13 @@ def main():
             if ctx is not None:
                 pa = make_problem(ctx)
                 for _ in range(8):
-                    pa.panoc_step()
+                    pa.panoc_step()      # (one step per call: plain launches, the reference for the check below)
                 sa = pa.panoc_scalars()
                 pa.close()
             sb = None
             try:
                 pb = make_problem(ctx2)
-                for _ in range(8):
-                    pb.panoc_step()
+                pb.panoc_steps(8)        # (the library's own loop, as in the timed region: gated pre-launch + mailboxes)
                 sb = pb.panoc_scalars()
                 pb.close()
                 if sa is not None:

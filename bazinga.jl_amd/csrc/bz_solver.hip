@@ -2071,6 +2071,13 @@ template <class T> class Solver final : public SolverBase {
                 gather(SL_AUX, 1, 1u);
                 if (collect({SL_AUX}, 1u)[0] > 0.0) persist_ok = false;
             }
+            // auto (lbfgs_compact = 2), one rank: wherever the two-loop would run as a CHAIN of 2m kernels (a vector beyond the
+            // persistent kernel's register capacity — e.g. the lifted vector [x; s] of ALS at n = 1e7 — or too short for its
+            // grid barriers) the compact form does the same work in two launches and 4m + 11 passes instead of 8m + 1
+            // (ALS at n = 1e7: 741 against 519 it/s).  Several ranks keep the rule above: they must agree on one form.
+            if (!compact_ok && o.lbfgs_compact == 2 && M >= 1 && M <= CM && dir_kind_ == BZ_DIR_LBFGS && !ctx->multi() && !persist_ok &&
+                !generic_)
+                compact_ok = true;
         }
         t_begin = std::chrono::steady_clock::now();
         k_ = 1; n_grad = n_prox = n_bt = n_halv = n_fused = n_skips = 0;

@@ -194,8 +194,12 @@ def cpu_baseline_oracle(workload, orc, n, ny, dtype, mu, y, x0, minimum_gamma, b
             blas_threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
         except Exception:      # noqa: BLE001
             blas_threads = os.cpu_count() or 1
-    al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
-    it = ref.PANOCplusIteration(al, ref.NonsmoothCostFun(orc[1]), x0, minimum_gamma=minimum_gamma)
+    if workload == "als":
+        al = ref.AugLagFunSlack(orc[0], orc[2], mu.copy(), y.copy(), x0[:n])
+        it = ref.PANOCplusIteration(al, ref.NonsmoothCostFunSlack(orc[1], orc[3], n, ny), x0, minimum_gamma=minimum_gamma)
+    else:
+        al = ref.AugLagFun(orc[0], orc[2], orc[3], mu.copy(), y.copy(), x0)
+        it = ref.PANOCplusIteration(al, ref.NonsmoothCostFun(orc[1]), x0, minimum_gamma=minimum_gamma)
     t0 = time.perf_counter()
     st = it.init()
     t_init = time.perf_counter() - t0
@@ -453,6 +457,7 @@ def side_workload(args):
     import bazinga_jl_amd as bz
     tuned = bz.runtime_tuning()
     eps64, eps32 = float(np.finfo(np.float64).eps), float(np.finfo(np.float32).eps)
+    slack = False
     if args.workload == "cfg3":
         d = bz.synth.obstacle_grid(2048)
         n = ny = 2048 * 2048
@@ -462,6 +467,18 @@ def side_workload(args):
         x0, mg = d["x0"], eps64
         ref_bytes = 63 * w * n            # 63 passes under the reference's dataflow
         label = "cfg3: 5-pt stencil QP on 2048^2 grid fp64, box D, g=Zero, LBFGS(5)"
+    elif args.workload == "als":
+        # the inner solve of Bazinga.als (src/algorithms/als.jl, src/utilities/auglagfunslack.jl) on the cfg 2
+        # data — the same PANOCplus on the lifted vector xs = [x; s] with the block prox [prox_g; proj_D]
+        n = ny = int(args.n or 10_000_000)
+        d = bz.synth.l1_quadratic(n)
+        dt, w = np.float64, 8
+        slack = True
+        oracles = lambda m: (m.DiagQuadratic(d["q"], d["b"]), m.NormL1(d["lam"]), m.IdentityFunction(),
+                             m.ClosedSet(m.IndBox(-1.0, 1.0)))
+        x0, mg = np.zeros(n + ny), eps64
+        ref_bytes = 65 * w * (n + ny)     # (the cfg 2 model of SURVEY 8(d) applied to the lifted vector: the reference runs the same solver on it)
+        label = "als: the slack form of cfg2 (l1-regularised diagonal quadratic, n=%d fp64, D=Box[-1,1]), inner vector [x; s], LBFGS(5)" % n
     else:
         ny, n = 8192, 65536
         d = bz.synth.basis_pursuit(ny, n, dtype=np.float32)
@@ -470,7 +487,7 @@ def side_workload(args):
         x0, mg = np.zeros(n, dt), eps32
         ref_bytes = 4 * ny * n * w        # A read twice per AL gradient, 2 AL gradients per iteration
         label = "cfg4: basis pursuit, dense A 8192x65536 fp32, l1 prox, D=ZeroSet, LBFGS(5)"
-    prob = bz.Problem(*oracles(bz), n, ny, dt)
+    prob = bz.Problem(*oracles(bz), n, ny, dt, slack=slack)
     mu, y = np.full(ny, 0.1, dt), np.zeros(ny, dt)
     prob.set_multipliers(mu, y)
     popts = bz.PANOCplus(tol=0.0, maxit=10 ** 12, minimum_gamma=mg,
@@ -540,7 +557,7 @@ def main():
     ap.add_argument("--n", "--size", dest="n", type=float, default=1e7,
                     help="global problem size (default: BASELINE cfg 2); spell it --size under torch.distributed.run, "
                          "whose own parser claims --n as an abbreviation")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "als"],
                     help="cfg2 (default, the headline metric); cfg3 2048^2 stencil QP; cfg4 dense-A basis "
                          "pursuit fp32; cfg5 = cfg2 at n=1e8")
     ap.add_argument("--family", default="diag-l1-box",
@@ -569,7 +586,7 @@ def main():
     n = int(args.n)
     if args.workload == "cfg5":
         n = 100_000_000
-    if args.workload in ("cfg3", "cfg4"):
+    if args.workload in ("cfg3", "cfg4", "als"):
         return side_workload(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -235,7 +235,10 @@ typedef struct {
                                    phase (one cross-GPU exchange) instead of 2M+1.  The same operator, an
                                    alternate rounding: its iterates track the fp64 oracle as closely as the
                                    two-loop kernels' do;
-                                2 (default): 1 where that one-pass kernel applies, 0 elsewhere.         */
+                                2 (default): 1 where that one-pass kernel applies, on the stencil and affine-image
+                                   paths, and — one rank — wherever the two-loop would otherwise run as a chain of 2M
+                                   kernels (a vector beyond the persistent launch's register capacity, or too short
+                                   for its grid barriers); 0 (the persistent two-loop launch) elsewhere.          */
     int32_t affine_refresh;  /* affine images (c = DenseAffine, D = ZeroSet / FreeSet, f = Zero / DiagQuadratic:
                                 c(.) and grad L(.) are affine maps).  k >= 1 (default 16): c(x + d) and grad L(x + d)
                                 are formed from the stored images of the iterates — the linear combination that

@@ -458,6 +458,7 @@ template <class T> class Solver final : public SolverBase {
     void alps(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0, const void* y0,
               void* xo, void* yo, void* so, void* muo, bz_alps_stats* st) override {
         if (slack) throw Error(BZ_ERR_STATE, "bz_alps_solve on a slack (ALS) problem: use bz_als_solve");
+        if (ao.warm_start & ~1) throw Error(BZ_ERR_ARG, "bz_alps_opts.warm_start: unknown bit (bit 0: the step size)");
         auto t0 = std::chrono::steady_clock::now();
         const T epsT = std::numeric_limits<T>::epsilon();
         T* x = X_[0].p;
@@ -587,6 +588,7 @@ template <class T> class Solver final : public SolverBase {
     void als(const bz_alps_opts& ao, const bz_panoc_opts& po, const void* x0, const void* y0,
              void* xo, void* yo, void* so, void* muo, bz_alps_stats* st) override {
         if (!slack) throw Error(BZ_ERR_STATE, "bz_als_solve needs a problem created with desc.slack = 1");
+        if (ao.warm_start & ~1) throw Error(BZ_ERR_ARG, "bz_alps_opts.warm_start: unknown bit (bit 0: the step size)");
         auto t0 = std::chrono::steady_clock::now();
         const T epsT = std::numeric_limits<T>::epsilon();
         T* xs = X_[0].p;                                   // [x; s]
@@ -1470,8 +1472,20 @@ template <class T> class Solver final : public SolverBase {
                     if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) break;
                 }
             }
-            if (!done) { gate_abort(); BZ_HIP(hipStreamSynchronize(cur_)); }
+            bool complete = done;
+            if (!done) {
+                gate_abort();
+                BZ_HIP(hipStreamSynchronize(cur_));
+                std::atomic_thread_fence(std::memory_order_acquire);
+                // everything queued has run: the scalars are there now, or they will never be (a device poll that gave
+                // up is reported below; anything else must not be read as numbers)
+                complete = true;
+                for (int i = 0; i < a.n; ++i)
+                    if ((ho[2 * i] & himask) != tag || (ho[2 * i + 1] & himask) != tag) { complete = false; break; }
+            }
             std::atomic_thread_fence(std::memory_order_acquire);
+            if (!complete && !*ptimeout_)
+                throw Error(BZ_ERR_HIP, "a read-back did not arrive although the stream is idle (no kernel posted these scalars)");
         }
         if (*ptimeout_) {
             const int code = *ptimeout_;

@@ -276,7 +276,7 @@ def alps(f, g, c, D, x0, y0, *, tol=None, tol_prim=None, tol_dual=None, inner_to
         ao.tol_prim, ao.tol_dual, ao.inner_tol = float(tol_prim), float(tol_dual), float(inner_tol)
         ao.maxit, ao.theta_penalty, ao.kappa_penalty = int(maxit), float(theta_penalty), float(kappa_penalty)
         ao.kappa_tol, ao.subsolver_maxit, ao.verbose = float(kappa_tol), int(subsolver_maxit), int(bool(verbose))
-        ao.warm_start = int(bool(warm_start))
+        ao.warm_start = int(warm_start)
         x, y, s, mu, st = prob.alps_solve(ao, sub.c_opts(), x0, y0)
         if problem is None:
             prob.close()

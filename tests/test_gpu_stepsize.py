@@ -134,6 +134,13 @@ def test_warm_started_alps_matches_the_warm_started_oracle(bz, ref, case):
     assert rel(a[0], o_cold[0]) <= 1e-4
 
 
+def test_unknown_warm_start_bits_are_refused(bz, ref):
+    n = 64
+    d, dev, orc = make_cfg2(bz, ref, n)
+    with pytest.raises(bz.BazingaHipError, match="warm_start"):
+        bz.alps(*dev, np.zeros(n), np.zeros(n), warm_start=2)
+
+
 def test_warm_start_saves_gradient_evaluations(bz, ref):
     """one Lipschitz estimate for the whole solve instead of one per subproblem"""
     ny, n = 20, 100

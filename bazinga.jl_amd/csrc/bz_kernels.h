@@ -2841,6 +2841,152 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------
+// The slack (ALS) form of the fused iteration, compact L-BFGS representation with stored pairs: the whole iteration of
+// PANOCplus on xs = [x; s] (src/algorithms/als.jl:68-72, src/utilities/auglagfunslack.jl:59-154) in ONE pass.  With
+// c = Identity and an element-wise f the lifted problem couples x_i with s_i only, so the chain
+//   d -> xs_d = xs + d -> grad F(xs_d) -> [prox_g; proj_D] -> grad F(z) -> pair -> stop norm
+// stays in registers per index i, as it does per element in k_fused_compact: reads res, S[m], Y[m], xs (both halves),
+// q, b, mu, mu*y, y; writes xs_d, z, res, s_new, y_new — (2m + 7) passes over the lifted vector + 5 over n instead
+// of the 4m + 24 of the kernel chain (k_compact_xd, k_algrad_slack_elem x 2, k_fbstep_slack, k_update_c).
+// Element arithmetic: that of k_algrad_slack_elem / k_fbstep_slack / k_update_c, operation for operation; the reductions
+// run over the index i with both halves' contributions, another summation tree than the chain's (which runs over the
+// lifted vector), so the scalars agree with it to rounding.  Slots: those of k_fused_compact.
+// ---------------------------------------------------------------------------
+template <class T> struct SlackOut { T gx, gs, fterm, pterm; };
+template <class T>
+__device__ __forceinline__ SlackOut<T> slack_elem(int f_kind, T x, T sv, T q, T b, T mu, T muy, T y) {
+    SlackOut<T> o;
+    T dfx = T(0);
+    o.fterm = T(0);
+    if (f_kind == BZ_F_DIAG_QUADRATIC) {
+        T qx = q * x;
+        dfx = qx - b;
+        o.fterm = x * (T(0.5) * qx - b);
+    }
+    const T cx = x;
+    T w = cx + muy;
+    w = w - sv;
+    o.pterm = (w * w) / mu;
+    const T r = cx - sv;
+    const T yupd = y + r / mu;
+    o.gx = dfx + yupd;
+    o.gs = -yupd;
+    return o;
+}
+template <class T, int MM, bool NT>
+__global__ void __launch_bounds__(BLOCK)
+k_fused_slack(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ xs, const T* __restrict__ res_prev,
+              ElemParams<T> P, const T* __restrict__ yv, T gamma, T* __restrict__ xs_d, T* __restrict__ z,
+              T* __restrict__ res, T* __restrict__ s_new, T* __restrict__ y_new, int64_t nx,
+              double* __restrict__ parts, int slot0) {
+    constexpr int N = PackN<T>::N;
+    const int m = V.m;
+    T u1[MM], u2h[MM];
+    compact_coefs<T, MM>(C, u1, u2h);
+    const T H0 = (T)C.H0;
+    const T gl = gamma * P.g_lambda;
+    constexpr int NS = 10 + 4 * MM + 2;
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
+        ElemLoads<T> L;
+        load_params<T, NT>(P, i0, cnt, L, true, true, true);
+        Pack<T> dlo = P.D_lo_vec ? ldp<T, NT>(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
+        Pack<T> dhi = P.D_hi_vec ? ldp<T, NT>(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
+        Pack<T> pyv = ldp<T, NT>(yv, i0, cnt);
+        // both halves of every lifted vector: h = 0 the x part, h = 1 the s part
+        Pack<T> px[2], prp[2], ps[2][MM], py[2][MM], d[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t o = i0 + (h ? nx : 0);
+            px[h] = ldp<T, NT>(xs, o, cnt);
+            prp[h] = ldp<T, NT>(res_prev, o, cnt);
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < m) { ps[h][i] = ldp<T, NT>(V.S[i], o, cnt); py[h][i] = ldp<T, NT>(V.Y[i], o, cnt); }
+            compact_d<T, MM>(m, H0, u1, u2h, prp[h], ps[h], py[h], d[h]);
+        }
+        Pack<T> pxd[2], pz[2], pr[2], pss[2], pyy[2];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const T xd = px[0].v[e] + d[0].v[e], sd = px[1].v[e] + d[1].v[e];
+            pxd[0].v[e] = xd; pxd[1].v[e] = sd;
+            // grad F(xs_d)   (k_algrad_slack_elem)
+            const SlackOut<T> o1 = slack_elem(P.f_kind, xd, sd, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], pyv.v[e]);
+            // forward-backward step   (k_fbstep_slack)
+            T t = gamma * o1.gx;
+            const T yx = xd - t;
+            T u = gamma * o1.gs;
+            const T ys = sd - u;
+            T gterm;
+            const T a = prox_elem(P.g_kind, yx, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            const T b = proj_D(P.D_kind, ys, dlo.v[e], dhi.v[e]);
+            const T r1 = xd - a, r2 = sd - b;
+            pz[0].v[e] = a; pz[1].v[e] = b; pr[0].v[e] = r1; pr[1].v[e] = r2;
+            // grad F(z)
+            const SlackOut<T> o2 = slack_elem(P.f_kind, a, b, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], pyv.v[e]);
+            // the pair and the stopping norm   (k_update_c)
+            const T sv0 = xd - px[0].v[e], sv1 = sd - px[1].v[e];
+            const T yy0 = r1 - prp[0].v[e], yy1 = r2 - prp[1].v[e];
+            pss[0].v[e] = sv0; pss[1].v[e] = sv1; pyy[0].v[e] = yy0; pyy[1].v[e] = yy1;
+            T w0 = r1 / gamma;
+            w0 = w0 - o1.gx;
+            w0 = w0 + o2.gx;
+            T w1 = r2 / gamma;
+            w1 = w1 - o1.gs;
+            w1 = w1 + o2.gs;
+            if (e < cnt) {
+                acc[0] += (double)o1.fterm;
+                acc[1] += (double)o1.pterm;
+                acc[2] += (double)gterm;
+                acc[3] += (double)(o1.gx * r1);
+                acc[3] += (double)(o1.gs * r2);
+                acc[4] += (double)(r1 * r1);
+                acc[4] += (double)(r2 * r2);
+                acc[5] += (double)o2.fterm;
+                acc[6] += (double)o2.pterm;
+                acc[7] += (double)(sv0 * yy0);
+                acc[7] += (double)(sv1 * yy1);
+                acc[8] += (double)(yy0 * yy0);
+                acc[8] += (double)(yy1 * yy1);
+                acc[9] = nanmax(acc[9], (double)(w0 < T(0) ? -w0 : w0));
+                acc[9] = nanmax(acc[9], (double)(w1 < T(0) ? -w1 : w1));
+                const T nr0 = T(-1) * r1, nr1 = T(-1) * r2;
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < m) {
+                        acc[10 + i] = mul_acc(ps[0][i].v[e], yy0, acc[10 + i]);
+                        acc[10 + i] = mul_acc(ps[1][i].v[e], yy1, acc[10 + i]);
+                        acc[10 + MM + i] = mul_acc(py[0][i].v[e], yy0, acc[10 + MM + i]);
+                        acc[10 + MM + i] = mul_acc(py[1][i].v[e], yy1, acc[10 + MM + i]);
+                        acc[10 + 2 * MM + i] = mul_acc(ps[0][i].v[e], nr0, acc[10 + 2 * MM + i]);
+                        acc[10 + 2 * MM + i] = mul_acc(ps[1][i].v[e], nr1, acc[10 + 2 * MM + i]);
+                        acc[10 + 3 * MM + i] = mul_acc(py[0][i].v[e], nr0, acc[10 + 3 * MM + i]);
+                        acc[10 + 3 * MM + i] = mul_acc(py[1][i].v[e], nr1, acc[10 + 3 * MM + i]);
+                    }
+                acc[10 + 4 * MM] = mul_acc(sv0, nr0, acc[10 + 4 * MM]);
+                acc[10 + 4 * MM] = mul_acc(sv1, nr1, acc[10 + 4 * MM]);
+                acc[10 + 4 * MM + 1] = mul_acc(yy0, nr0, acc[10 + 4 * MM + 1]);
+                acc[10 + 4 * MM + 1] = mul_acc(yy1, nr1, acc[10 + 4 * MM + 1]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t o = i0 + (h ? nx : 0);
+            stp<T, NT>(xs_d, o, cnt, pxd[h]);
+            if (z) stp<T, NT>(z, o, cnt, pz[h]);
+            stp<T, NT>(res, o, cnt, pr[h]);
+            stp<T, NT>(s_new, o, cnt, pss[h]);
+            stp<T, NT>(y_new, o, cnt, pyy[h]);
+        }
+    });
+    if constexpr (NS == 32) block_reduce_store32(acc, 1u << 9, parts, slot0);
+    else block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------
 // K6: x = tau*x_d + (1-tau)*z_curr

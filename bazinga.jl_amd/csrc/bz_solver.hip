@@ -2050,7 +2050,8 @@ template <class T> class Solver final : public SolverBase {
         if (o.adaptive < -1 || o.adaptive > 1) throw Error(BZ_ERR_ARG, "adaptive must be -1 (default), 0 or 1");
         gamma_given_ = o.gamma > 0.0 ? (T)o.gamma : (o.Lf > 0.0 ? alpha / (T)o.Lf : T(0));
         adaptive_ = o.adaptive < 0 ? !(gamma_given_ > T(0)) : o.adaptive != 0;
-        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && !slack &&
+        // (the slack form of ALS too: x_i couples with s_i only — k_fused_slack; no pairwise D there, it needs the partner)
+        fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && (!slack || desc.D_kind < BZ_D_VC_PAIRS) &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
         // auto: the compact representation where it makes the whole iteration one pass (the fused separable
         // path, memory within its capacity), the two-loop recursion everywhere else
@@ -2444,7 +2445,20 @@ template <class T> class Solver final : public SolverBase {
 #define BZ_LAUNCH_FC3(NT_)                                                                                        \
     launch(C_FUSED, k_fused_compact<T, CM, NT_, true, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P, \
            gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL)
-            {
+            if (slack) {
+                // the lifted vector [x; s]: res, S[m], Y[m], xs ; xs_d, res, s_new, y_new (z) — both halves — and over n the
+                // parameter vectors and the multipliers y
+                mv(2 * (2 + 2 * CV.m + 4 + (zstore ? 1 : 0)) + pstreams(true, true, true) + 1, nx);
+                form_[C_FUSED] = std::string("k_fused_slack") + (nt ? "<NT=1>" : "<NT=0>");
+                if (nt)
+                    launch(C_FUSED, k_fused_slack<T, CM, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
+                           (const T*)ymul_.p, gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, nx, parts_.p,
+                           (int)SL_TRIAL);
+                else
+                    launch(C_FUSED, k_fused_slack<T, CM, false>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,
+                           (const T*)ymul_.p, gamma, X_[xd].p, zstore, RES_[rn].p, S_[spare].p, Y_[spare].p, nx, parts_.p,
+                           (int)SL_TRIAL);
+            } else {
                 // stored pairs: res, S[m], Y[m], x + the parameter vectors ; x_d, res, s_new, y_new (z)
                 mv(2 + 2 * CV.m + pstreams(true, true, true) + 4 + (zstore ? 1 : 0));
                 form_[C_FUSED] = std::string("k_fused_compact<XR=0") + (spec ? ",SPEC=1" : ",SPEC=0") + (nt ? ",NT=1>" : ",NT=0>");
@@ -2481,7 +2495,7 @@ template <class T> class Solver final : public SolverBase {
             if (have_plan) gate_prelaunch(nxt);
             have_trial = true; fused_this = true; gx_valid = false; gz_valid = false; gram_from_trial = true;
             n_grad += 2; n_prox += 1;
-        } else if (fused_ok) {
+        } else if (fused_ok && !slack) {
             if (!res_valid) ensure_z();
             for (int k = 0; k < 12; ++k) slot_n[SL_TRIAL + k] = grid;
             mv((tail.mode != 2 ? 2 : 1) + 2 + pstreams(true, true, true) + 5);

@@ -85,6 +85,47 @@ def test_als_matches_oracle_and_alps(bz, ref, resident):
     assert not np.any(x0)
 
 
+@pytest.mark.parametrize("D", ["box", "free"])
+@pytest.mark.parametrize("n", [4098, 150_001 * 2])
+def test_fused_slack_pass_follows_the_kernel_chain(bz, ref, n, D):
+    """k_fused_slack (the whole ALS inner iteration on [x; s] in one pass, compact L-BFGS form) against the kernel chain
+    (fuse = False: k_compact_xd, k_algrad_slack_elem x 2, k_fbstep_slack, k_update_c): the same element arithmetic,
+    reductions over the index instead of over the lifted vector — 40 states agree to rounding, the one-pass kernel
+    serves the iterations, and the oracle's ALS inner iterates are followed to the north-star tolerance."""
+    d, dev, orc = make_cfg2(bz, ref, n, D=D)
+    rng = np.random.default_rng(5)
+    mu, y = np.full(n, 0.1), 0.3 * rng.standard_normal(n)
+    xs0 = np.concatenate([0.05 * rng.standard_normal(n), np.zeros(n)])
+    runs = []
+    for fuse in (True, False):
+        prob = bz.Problem(*dev, n, n, np.float64, slack=True)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse, minimum_gamma=float(np.finfo(float).eps)).c_opts(), xs0)
+        prob.profile_enable(True)
+        tr = []
+        for k in range(40):
+            prob.panoc_step()
+            if k in (0, 5, 15, 39):
+                tr.append((prob.panoc_vector("x"), prob.panoc_scalars()))
+        runs.append((tr, prob.panoc_stats(), prob.profile2()))
+        prob.close()
+    (ta, sa, pa), (tb, sb, pb) = runs
+    assert sa.n_fused_iters >= 30 and sb.n_fused_iters == 0
+    assert pa["k_fused_sep"]["form"].startswith("k_fused_slack") and pa["k_fused_sep"]["launches"] >= 30
+    for (xa, ca), (xb, cb) in zip(ta, tb):
+        assert ca["gamma"] == cb["gamma"] and ca["lbfgs_mem"] == cb["lbfgs_mem"]
+        assert np.max(np.abs(xa - xb)) <= 1e-10 * max(1.0, np.max(np.abs(xb)))
+        assert abs(ca["stop_norm"] - cb["stop_norm"]) <= 1e-8 * max(1.0, cb["stop_norm"])
+    # ... and the oracle
+    al = ref.AugLagFunSlack(orc[0], orc[2], mu.copy(), y.copy(), xs0[:n])
+    it = ref.PANOCplusIteration(al, ref.NonsmoothCostFunSlack(orc[1], orc[3], n, n), xs0,
+                                minimum_gamma=float(np.finfo(float).eps))
+    st = it.init()
+    for k in range(16):
+        st = it.step(st)
+    assert np.max(np.abs(ta[2][0] - st.x)) <= 1e-10 * max(1.0, np.max(np.abs(st.x)))
+
+
 def test_als_warm_start_matches_the_warm_started_oracle(bz, ref):
     """als(warm_start=True) (bz_alps_opts.warm_start through bz_als_solve): the step size carried across subproblems, as
     in alps — the resident loop against the oracle restated with the same option; the host loop refuses it."""

@@ -66,6 +66,9 @@ def form_of(kernel):
     m = re.match(r"(k_compact_xd|k_stencil_update_c)<\w+, \d+(?:, (true|false), (true|false))?>$", k)
     if m:
         return f"{m.group(1)}<FULL={int(m.group(2) == 'true')},NT={int(m.group(3) == 'true')}>"
+    m = re.match(r"k_fused_slack<\w+, \d+, (true|false)>$", k)
+    if m:
+        return f"k_fused_slack<NT={int(m.group(1) == 'true')}>"
     m = re.match(r"k_stencil_fb<\w+(?:, (true|false))?>$", k)
     if m:
         return f"k_stencil_fb<NT={int(m.group(1) == 'true')}>"

@@ -621,6 +621,7 @@ template <class T> class Solver final : public SolverBase {
             begin_dev(po2, xs);                                      // sub_solver(f=fSlack, g=gSlack, x0=xSlack)
             run_to_completion();
             const int64_t sub_it = k_;
+            ensure_z();                                              // (the one-pass kernel keeps z in registers until it is asked for)
             xs = Z_[zc].p;                                           // xSlack .= sub_sol
             objx = fraw_last + g_z;                                  // f(x) + gSlack.gz       als.jl:79
             tot_inner += sub_it;
@@ -2186,7 +2187,9 @@ template <class T> class Solver final : public SolverBase {
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));
             // (upstream: `if (iter.gamma === nothing || iter.adaptive == true)` backtrack_stepsize!)
-            if (adaptive_ && f_z > f_z_upp + tol && gamma >= min_gamma) {
+            // (an infinite gamma — a zero Lipschitz estimate: grad F(x + 1) = grad F(x), e.g. f = Zero in the slack form — cannot be
+            // halved: the reference's loop compares NaNs there and leaves; here f(z) may come out +inf, so say it explicitly)
+            if (adaptive_ && std::isfinite((double)gamma) && f_z > f_z_upp + tol && gamma >= min_gamma) {
                 gamma = gamma / T(2); ++n_halv;
                 continue;
             }
@@ -2681,7 +2684,7 @@ template <class T> class Solver final : public SolverBase {
             const T nr = std::sqrt(ss_res);
             const T f_z_upp = f_x - dot_gr + ((alpha / gamma) / T(2)) * (nr * nr);
             const T tol = T(10) * eps * (T(1) + std::abs(f_z));
-            const bool halve = adaptive_ && f_z > f_z_upp + tol && gamma >= min_gamma;
+            const bool halve = adaptive_ && std::isfinite((double)gamma) && f_z > f_z_upp + tol && gamma >= min_gamma;
             if (halve && img_trial) {
                 // The step-size test compares f(z) with a model built on f(x) and grad L(x) to within 10 eps: an image
                 // (a linear combination, not an evaluation) is not consistent with f(z) to that level near convergence,

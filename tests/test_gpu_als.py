@@ -126,6 +126,23 @@ def test_fused_slack_pass_follows_the_kernel_chain(bz, ref, n, D):
     assert np.max(np.abs(ta[2][0] - st.x)) <= 1e-10 * max(1.0, np.max(np.abs(st.x)))
 
 
+def test_als_long_subproblems_through_the_fused_pass(bz, ref):
+    """Subproblems of several hundred iterations (the one-pass kernel then keeps z in registers: the outer loop must ask
+    for it — it once read a stale buffer here, tests/stress/stress_als.py seed 26): the closed form of min f + g when D is
+    the whole space, the oracle's counts loosely (the usual chaos of long subsolves), its point to the solve's tolerance."""
+    rng = np.random.default_rng(7026)
+    n = 4834
+    q, b = rng.uniform(0.2, 5.0, n), rng.standard_normal(n) * 4
+    lam = 1.7
+    x0, y0 = rng.standard_normal(n) * 0.1, rng.standard_normal(n) * 0.1
+    o = ref.als(ref.DiagQuadratic(q, b), ref.NormL1(lam), ref.IdentityFunction(), ref.FreeSet(), x0, y0, maxit=40)
+    a = bz.als(bz.DiagQuadratic(q, b), bz.NormL1(lam), bz.IdentityFunction(), bz.FreeSet(), x0, y0, maxit=40)
+    xs = np.sign(b) * np.maximum(np.abs(b) - lam, 0) / q
+    assert a[5] == o[5] == "first_order" and abs(a[2] - o[2]) <= 1
+    assert o[3] >= 1000 and abs(a[3] - o[3]) <= 0.3 * o[3]
+    assert np.max(np.abs(a[0] - xs)) <= 2e-5 and np.max(np.abs(a[0] - o[0])) <= 2e-5
+
+
 def test_als_warm_start_matches_the_warm_started_oracle(bz, ref):
     """als(warm_start=True) (bz_alps_opts.warm_start through bz_als_solve): the step size carried across subproblems, as
     in alps — the resident loop against the oracle restated with the same option; the host loop refuses it."""

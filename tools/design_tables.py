@@ -22,7 +22,7 @@ def main():
 | cfg 2, two-loop recursion (`two_loop`) | {c2['two_loop']['value']:.0f} [1940–2050] | {c2['two_loop']['ms_per_step']:.3f} | `k_twoloop_persist` + `k_fused_sep` (11 streams with the penalties as numbers) | — | |
 | cfg 2 inside outer iteration 3 (`outer3`, y ≠ 0: 10 passes) | {c2['outer3']['value']:.0f} [6340–6700] | {c2['outer3']['ms_per_step']:.3f} | same kernel, UNI=1 | — | |
 | cfg 2, whole `alps` (`whole_alps`) | {wa['device_pointers']['value']:.0f} inner it/s with device pointers ({wa['device_pointers']['ms']:.1f} ms for 13 outer / 180 inner) [5400–5860]; {wa['host_pageable']['value']:.0f} from pageable host arrays ({wa['host_pageable']['ms']:.1f} ms); `warm_start`: {wa['device_pointers_warm_start']['inner']} inner iterations in {wa['device_pointers_warm_start']['ms']:.1f} ms | | | | |
-| cfg 3 2048² stencil fp64, compact form (default) | **{c3['value']:.0f}** ({c3['repeats']['value_median']:.0f}) [4140–4360] — start of the round: 3190–3270 | {c3['ms_per_step']:.4f} | `k_stencil_update_c<FULL=1,NT=1>` {r(c3)['avg_launch_us']:.1f} µs, 0.671 GB → {r(c3)['frac']:.2f} (PMC {r(c3)['traffic'] / 1e9:.4f} GB, ratio {r(c3)['wasted_traffic_ratio']:.3f}); `k_compact_xd<FULL=1,NT=1>` {k3['x_d']['avg_us']:.1f} µs → {k3['x_d']['moved_GBps'] / 8000:.2f} (partly out of the Infinity Cache); `k_stencil_fb<NT=1>` {k3['k_stencil_fb']['avg_us']:.1f} µs → {k3['k_stencil_fb']['moved_GBps'] / 8000:.2f} | **{c3['roofline_iteration']['frac']:.2f}** [0.68–0.71] | {c3['cpu_baseline']['value']:.1f} it/s (numpy) |
+| cfg 3 2048² stencil fp64, compact form (default) | **{c3['value']:.0f}** ({c3['repeats']['value_median']:.0f}) [4100–4360] — start of the round: 3190–3270 | {c3['ms_per_step']:.4f} | `k_stencil_update_c<FULL=1,NT=1>` {r(c3)['avg_launch_us']:.1f} µs, 0.671 GB → {r(c3)['frac']:.2f} (PMC {r(c3)['traffic'] / 1e9:.4f} GB, ratio {r(c3)['wasted_traffic_ratio']:.3f}); `k_compact_xd<FULL=1,NT=1>` {k3['x_d']['avg_us']:.1f} µs → {k3['x_d']['moved_GBps'] / 8000:.2f} (partly out of the Infinity Cache); `k_stencil_fb<NT=1>` {k3['k_stencil_fb']['avg_us']:.1f} µs → {k3['k_stencil_fb']['moved_GBps'] / 8000:.2f} | **{c3['roofline_iteration']['frac']:.2f}** [0.68–0.71] | {c3['cpu_baseline']['value']:.1f} it/s (numpy) |
 | cfg 3, two-loop kernels (`--two-loop`) | {c3t['value']:.0f} ({c3t['repeats']['value_median']:.0f}) [3620–3730] | {c3t['ms_per_step']:.3f} | `k_twoloop_persist<KR=16>` {r(c3t)['avg_launch_us']:.1f} µs → {r(c3t)['frac']:.2f} | {c3t['roofline_iteration']['frac']:.2f} | |
 | cfg 4 8192×65536 fp32, affine images (default, `affine_refresh` = 16) | **{c4['value']:.0f}** [1098–1110; 979–1011 at refresh 8] (r01: 585–628) | {c4['ms_per_step']:.3f} | `k_gemv_n` {r(c4)['avg_launch_us']:.1f} µs per 2 GiB pass → {r(c4)['frac']:.2f} (PMC {r(c4)['traffic'] / 1e9:.4f} GB, ratio {r(c4)['wasted_traffic_ratio']:.4f}); `k_gemv_t_mfma` {r(c4)['other_gemv']['k_gemv_t_mfma']['avg_launch_us']:.1f} µs → {r(c4)['other_gemv']['k_gemv_t_mfma']['achieved'] / 8000:.2f} | {c4['roofline_iteration']['frac']:.2f} | {c4['cpu_baseline']['value']:.1f} it/s (numpy, BLAS 64 threads) |
 | ALS inner solve (`--workload als`, SURVEY §8(f-3)): cfg 2 in slack form, inner vector [x; s] of 2·10⁷ | **{ca['value']:.0f}** (766 with the compact form as a kernel chain, 519 with the two-loop chain: the stages of this round) | {ca['ms_per_step']:.3f} | `k_fused_slack<NT=1>` {r(ca)['avg_launch_us']:.0f} µs, {r(ca)['moved_bytes_per_launch'] / 1e9:.2f} GB → {r(ca)['frac']:.2f}{(" (PMC ratio %.4f)" % r(ca)['wasted_traffic_ratio']) if r(ca).get('wasted_traffic_ratio') else ""}: the whole iteration in one pass, 17 passes over the lifted vector + 5 over n | {ca['roofline_iteration']['frac']:.2f} | {ca['cpu_baseline']['value']:.2f} it/s (numpy) |

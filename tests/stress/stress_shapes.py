@@ -38,7 +38,7 @@ for i in range(40):
 print("done; failures:", bad)
 for i in range(25):
     nx = int(rng.integers(2, 120)); ny = 2 * int(rng.integers(1, 120))
-    run("stencil-panoc", raw(T.test_stencil_panoc_iterates_match_oracle), (nx, ny), 15)
+    run("stencil-panoc", raw(T.test_stencil_panoc_iterates_match_oracle), (nx, ny), 15, str(rng.choice(["default", "two-loop"])))
 for i in range(12):
     n = int(rng.integers(1, 50000))
     run("panoc", raw(T.test_panoc_iterates_match_oracle), n, str(rng.choice(["box", "free"])),

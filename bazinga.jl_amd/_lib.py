@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbazinga_hip.so")
 
 BZ_OK = 0
-BZ_ERR_ARG, BZ_ERR_HIP, BZ_ERR_UNSUPPORTED, BZ_ERR_STATE, BZ_ERR_COMM, BZ_ERR_MU = -1, -2, -3, -4, -5, -6
+BZ_ERR_ARG, BZ_ERR_HIP, BZ_ERR_UNSUPPORTED, BZ_ERR_STATE, BZ_ERR_COMM, BZ_ERR_MU, BZ_ERR_CALLBACK = -1, -2, -3, -4, -5, -6, -7
 BZ_F64, BZ_F32 = 0, 1
 BZ_F_ZERO, BZ_F_DIAG_QUADRATIC, BZ_F_STENCIL5, BZ_F_LEAST_SQUARES, BZ_F_QUADRATIC = 0, 1, 2, 3, 4
 BZ_G_ZERO, BZ_G_NORM_L1, BZ_G_NORM_L1_NONNEG, BZ_G_NORM_L1_BOX, BZ_G_IND_BOX, BZ_G_NORM_L0_BOX = 0, 1, 2, 3, 4, 5
@@ -139,6 +139,7 @@ SIGNATURES = {
     "bz_profile_reset": (C.c_int, [_vp]),
     "bz_profile_get2": (C.c_int, [_vp, C.c_int32, _P(ProfileRec)]),
     "bz_runtime_tuning": (C.c_int, []),
+    "bz_callback_abort": (None, []),
 }
 
 _lib = None

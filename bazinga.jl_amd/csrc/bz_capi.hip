@@ -52,7 +52,10 @@ template <class F> int guard(F&& f) {
 // HIP's current device is per host thread: every entry point that takes a handle selects the handle's device
 // first (a caller on another thread — a migrated Julia task, a Python worker — would otherwise allocate and
 // launch on device 0)
-void on_device(int device) { BZ_HIP(hipSetDevice(device)); }
+void on_device(int device) {
+    bz::callback_abort_flag() = false;      // (a stale request from outside any library call)
+    BZ_HIP(hipSetDevice(device));
+}
 void need(const void* p, const char* what) {
     if (!p) throw bz::Error(BZ_ERR_ARG, std::string("null argument: ") + what);
 }
@@ -63,6 +66,7 @@ extern "C" {
 const char* bz_last_error(void) { return g_err.c_str(); }
 const char* bz_version(void) { return "bazinga-hip 0.2 (gfx950)"; }
 int bz_runtime_tuning(void) { return apply_runtime_tuning(); }
+void bz_callback_abort(void) { bz::callback_abort_flag() = true; }
 
 int bz_comm_unique_id(void* id128) {
     return guard([&] {

@@ -141,6 +141,7 @@ struct SolverBase {
     virtual void profile_get2(int cat, bz_profile_rec* out) = 0;
 };
 
+bool& callback_abort_flag();      // thread-local: bz_callback_abort() was called (generic oracles)
 void p2p_export(Ctx* ctx, void* handle64);
 void p2p_connect(Ctx* ctx, const void* handles, const int32_t* devices);
 

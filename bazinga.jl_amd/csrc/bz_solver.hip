@@ -104,6 +104,12 @@ struct PersistTimeout : Error {
     PersistTimeout() : Error(BZ_ERR_HIP, "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)") {}
 };
 
+// set by bz_callback_abort() from inside a host callback (callbacks run on the thread that made the library call)
+bool& callback_abort_flag() {
+    static thread_local bool flag = false;
+    return flag;
+}
+
 enum Cat : int { C_TWOLOOP = 0, C_FUSED = 1, C_ALGRAD = 2, C_FB = 3, C_UPDATE = 4,
                  C_COLLECT = 5, C_GATHER = 6, C_MISC = 7, C_DOT = 8, C_GEMV = 9, C_PERSIST = 10, C_GEMV_MFMA = 11, C_FUSED_IT = 12,
                  C_STENCIL_FB = 13, C_STENCIL_UPD = 14, C_XD = 15 };
@@ -479,8 +485,8 @@ template <class T> class Solver final : public SolverBase {
             // eval!(cx, c, x) ; proj!(s, D, cx) ; default_penalty_parameter!   (alps.jl:40-42, safeguards.jl:13-18:
             // Float64 literals, stored back into T — the arithmetic of k_penalty_init)
             copy_out(hx_.data(), x, n);
-            desc.cb_c_eval(desc.cb_user, hx_.data(), hcx_.data(), n, ny);
-            desc.cb_D_proj(desc.cb_user, hcx_.data(), hs_.data(), ny);
+            cb_c_eval(hx_.data(), hcx_.data(), n, ny);
+            cb_D_proj(hcx_.data(), hs_.data(), ny);
             for (int64_t i = 0; i < ny; ++i) {
                 const T dd = hcx_[i] - hs_[i];
                 const double h = 0.5 * (double)(dd * dd);
@@ -529,9 +535,9 @@ template <class T> class Solver final : public SolverBase {
             if (dense_c) eval_c(x);                                  // eval!(cx, c, x)  alps.jl:72
             if (generic_) {
                 copy_out(hx_.data(), x, n);
-                desc.cb_c_eval(desc.cb_user, hx_.data(), hcx_.data(), n, ny);          // eval!(cx, c, x)      alps.jl:72
+                cb_c_eval(hx_.data(), hcx_.data(), n, ny);          // eval!(cx, c, x)      alps.jl:72
                 for (int64_t i = 0; i < ny; ++i) hyv_[i] = hcx_[i] + hmuy_[i];         // y .= cx .+ muy       :74
-                desc.cb_D_proj(desc.cb_user, hyv_.data(), hs_.data(), ny);             // proj!(s, D, y)       :75
+                cb_D_proj(hyv_.data(), hs_.data(), ny);             // proj!(s, D, y)       :75
                 double nrm = 0.0;
                 for (int64_t i = 0; i < ny; ++i) {
                     T t = hyv_[i] - hs_[i];                                            // y .-= s              :80
@@ -682,6 +688,17 @@ template <class T> class Solver final : public SolverBase {
     // generic oracles (host callbacks): host mirrors of the vectors the callbacks read and write
     bool generic_ = false;
     std::vector<T> hx_, hg_, hy_, hz_, hres_, hdfx_, hjtv_, hcx_, ht_, hs_, hmu_, hmuy_, hyv_;
+    // the five host callbacks; a callback that failed says so through bz_callback_abort() (it cannot unwind through the
+    // C frames): the library call in progress then ends with BZ_ERR_CALLBACK as soon as the callback has returned,
+    // instead of iterating on whatever the failed callback left in its output buffers
+    static void cb_check() {
+        if (callback_abort_flag()) { callback_abort_flag() = false; throw Error(BZ_ERR_CALLBACK, "an oracle callback failed (bz_callback_abort)"); }
+    }
+    void cb_c_eval(const T* x, T* cx, int64_t n_, int64_t ny_) { desc.cb_c_eval(desc.cb_user, x, cx, n_, ny_); cb_check(); }
+    void cb_D_proj(const T* v, T* s, int64_t ny_) { desc.cb_D_proj(desc.cb_user, v, s, ny_); cb_check(); }
+    void cb_c_jtprod(const T* x, const T* v, T* jtv, int64_t n_, int64_t ny_) { desc.cb_c_jtprod(desc.cb_user, x, v, jtv, n_, ny_); cb_check(); }
+    double cb_f_gradient(const T* x, T* dfx, int64_t n_) { const double v = desc.cb_f_gradient(desc.cb_user, x, dfx, n_); cb_check(); return v; }
+    double cb_g_prox(const T* x, double gam, T* z, int64_t n_) { const double v = desc.cb_g_prox(desc.cb_user, x, gam, z, n_); cb_check(); return v; }
     void fill_slot(int slot, double v) {
         launch_b(C_MISC, k_fill_slot, 1, 64, parts_.p, slot, v);
         slot_n[slot] = 1;
@@ -690,18 +707,18 @@ template <class T> class Solver final : public SolverBase {
     // src/utilities/auglagfun.jl:73-86 (the value-only form :58-69 is the same minus dfx and jtv)
     void algrad_generic(const T* x, T* grad, int slot0) {
         copy_out(hx_.data(), x, n);
-        desc.cb_c_eval(desc.cb_user, hx_.data(), hcx_.data(), n, ny);                  // eval!(cx, c, x)          :74
+        cb_c_eval(hx_.data(), hcx_.data(), n, ny);                  // eval!(cx, c, x)          :74
         for (int64_t i = 0; i < ny; ++i) ht_[i] = hcx_[i] + hmuy_[i];                  // yupd .= cx .+ muy        :75
-        desc.cb_D_proj(desc.cb_user, ht_.data(), hs_.data(), ny);                      // proj!(s, D, yupd)        :76
+        cb_D_proj(ht_.data(), hs_.data(), ny);                      // proj!(s, D, yupd)        :76
         double pen = 0.0;
         for (int64_t i = 0; i < ny; ++i) {
             T t = ht_[i] - hs_[i];                                                     // yupd .-= s               :77
             pen += (double)((t * t) / hmu_[i]);                                        // sum(yupd.^2 ./ mu)       :78
             ht_[i] = t / hmu_[i];                                                      // yupd ./= mu              :79
         }
-        const double fx = desc.cb_f_gradient(desc.cb_user, hx_.data(), hdfx_.data(), n);   // fx = gradient!(dfx, f, x)  :80
+        const double fx = cb_f_gradient(hx_.data(), hdfx_.data(), n);   // fx = gradient!(dfx, f, x)  :80
         if (grad) {
-            desc.cb_c_jtprod(desc.cb_user, hx_.data(), ht_.data(), hjtv_.data(), n, ny);   // jtprod!(jtv, c, x, yupd)   :83
+            cb_c_jtprod(hx_.data(), ht_.data(), hjtv_.data(), n, ny);   // jtprod!(jtv, c, x, yupd)   :83
             for (int64_t j = 0; j < n; ++j) hg_[j] = hdfx_[j] + hjtv_[j];              // dlx .= dfx .+ jtv        :84
             copy_in(grad, hg_.data(), n);
         }
@@ -718,7 +735,7 @@ template <class T> class Solver final : public SolverBase {
             if (g) { T t = gam * hg_[j]; yv = hx_[j] - t; }
             hy_[j] = yv;
         }
-        const double gz = desc.cb_g_prox(desc.cb_user, hy_.data(), (double)gam, hz_.data(), n);
+        const double gz = cb_g_prox(hy_.data(), (double)gam, hz_.data(), n);
         double dot = 0.0, ss = 0.0;
         for (int64_t j = 0; j < n; ++j) {
             const T r = hx_[j] - hz_[j];
@@ -800,6 +817,7 @@ template <class T> class Solver final : public SolverBase {
     int xr_run_ = 0;             // consecutive plain, pair-inserting iterations so far
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
+    int nt_env_ = -1;            // BZ_NT: -1 (default) non-temporal streams by working-set size, 0 / 1 forced
     int famrt_env_ = 0;          // BZ_FAMRT=1: the headline family through its family-table instantiation (run-time UNI / TRIAL)
     bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
     bool rh_stale_ = false;      // ... and the residual ring was not written either during this run
@@ -989,7 +1007,7 @@ template <class T> class Solver final : public SolverBase {
         const int fam = fused_family();
         static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
         static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;
-        static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
+        const int nt_env = nt_env_;
         const bool small = off32_env && (double)vcap * sizeof(T) < 4.0e9;
         if (!(xr_env_ >= 2 && small && fam >= 0 && xr_run >= m_now)) return false;
         for (int i = 1; i < m_now; ++i)
@@ -1653,7 +1671,7 @@ template <class T> class Solver final : public SolverBase {
     void fvalue(const T* x, int slot0) {
         if (generic_) {      // f(x) through the gradient callback (the reference's generic f(x) needs no more)
             copy_out(hx_.data(), x, n);
-            fill_slot(slot0, desc.cb_f_gradient(desc.cb_user, hx_.data(), hdfx_.data(), n));
+            fill_slot(slot0, cb_f_gradient(hx_.data(), hdfx_.data(), n));
             return;
         }
         slot_n[slot0] = grid;
@@ -2050,7 +2068,9 @@ template <class T> class Solver final : public SolverBase {
         if (o.gamma < 0.0 || o.Lf < 0.0 || o.gamma != o.gamma || o.Lf != o.Lf) throw Error(BZ_ERR_ARG, "gamma and Lf must be >= 0 (0 = nothing)");
         if (o.adaptive < -1 || o.adaptive > 1) throw Error(BZ_ERR_ARG, "adaptive must be -1 (default), 0 or 1");
         gamma_given_ = o.gamma > 0.0 ? (T)o.gamma : (o.Lf > 0.0 ? alpha / (T)o.Lf : T(0));
-        adaptive_ = o.adaptive < 0 ? !(gamma_given_ > T(0)) : o.adaptive != 0;
+        // (upstream tests `iter.gamma === nothing || iter.adaptive == true` at both halving sites: without a given step
+        // size the estimate is always backtracked, whatever `adaptive` says)
+        adaptive_ = !(gamma_given_ > T(0)) || o.adaptive == 1;
         // (the slack form of ALS too: x_i couples with s_i only — k_fused_slack; no pairwise D there, it needs the partner)
         fused_ok = o.fuse && desc.c_kind == BZ_C_IDENTITY && !lp_g && (!slack || desc.D_kind < BZ_D_VC_PAIRS) &&
                    (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
@@ -2105,9 +2125,13 @@ template <class T> class Solver final : public SolverBase {
         fused_begin_env_ = std::getenv("BZ_FUSED_BEGIN") ? std::atoi(std::getenv("BZ_FUSED_BEGIN")) : 1;
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
+        nt_env_ = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
-        gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : 1;
+        // Several ranks: off unless asked for (BZ_GATE=1).  A launch that misses its gate cannot be redone there (the peers
+        // have consumed this rank's scalars: BZ_ERR_COMM), and gated launches on distinct devices have never run on
+        // hardware — bench.py asks for them after checking, on the node it runs on, that they reproduce the plain launches.
+        gate_env_ = std::getenv("BZ_GATE") ? std::atoi(std::getenv("BZ_GATE")) : (ctx->nranks > 1 ? 0 : 1);
         // a resident launch polling at its gate holds its CUs: with another tenant on the GPU (a rank of this very job in
         // a one-GPU rehearsal, or whoever made an earlier launch of this problem miss its gate) the two starve each other
         if (ctx->shared_device || gate_broken_) gate_env_ = 0;
@@ -2214,6 +2238,7 @@ template <class T> class Solver final : public SolverBase {
     }
 
     void run_to_completion() {
+        LoopGuard guard{this};
         for (;;) {
             const bool stop = should_stop();
             if (stop) gate_abort();              // (a pass pre-launched for an iteration that will not happen)
@@ -2222,8 +2247,6 @@ template <class T> class Solver final : public SolverBase {
             more_coming_ = k_ + 1 < opt.maxit;   // the solver's own loop: another iteration follows unless this one stops it
             step();
         }
-        more_coming_ = false;
-        gate_quiesce();
     }
 
     void display() {
@@ -2239,59 +2262,69 @@ template <class T> class Solver final : public SolverBase {
 
     // ---------------------------------------- Base.iterate(iter, state)  (k += 1)
    public:
+    // (leaving a library-run loop, normally or by an exception: no pass stays pre-launched at its gate, the flag that
+    // allows pre-launching is down, the solver is back on the context's stream)
+    struct LoopGuard {
+        Solver* s;
+        ~LoopGuard() {
+            s->more_coming_ = false;
+            try { s->gate_quiesce(); } catch (...) {}
+        }
+    };
     void steps(int64_t k) override {
+        LoopGuard guard{this};
         for (int64_t i = 0; i < k; ++i) {
             more_coming_ = i + 1 < k;            // (the caller asked for all k: the next pass may be launched early)
             step();
         }
-        more_coming_ = false;
-        gate_quiesce();
     }
     void step() override {
         require_active();
-        if (!persist_ok) {
-            try {
-                step_impl();
-            } catch (...) {
-                try { gate_quiesce(); } catch (...) {}
-                throw;
-            }
-            if (!more_coming_) gate_quiesce();
-            return;
-        }
-        // a grid barrier of the persistent two-loop kernel that cannot complete (its workgroups are not all
-        // resident: another stream or process holds CUs) is reported through the next read-back; nothing of the
-        // state has been committed by then, so the iteration is simply redone with the kernel chain, and the
-        // persistent form stays off for this problem
+        // Two things can make an iteration fail without having committed anything of the state, and both are reported
+        // through the next read-back: a grid barrier of the persistent two-loop kernel that cannot complete (its
+        // workgroups are not all resident: another stream or process holds CUs), and a pass pre-launched behind its gate
+        // that gave up there (the host was descheduled for seconds, or the GPU has another tenant).  The iteration is
+        // simply redone — with the kernel chain, without the gate — and the form that failed stays off for this
+        // problem.  Whatever else goes wrong leaves with no launch waiting at a gate.
         const int64_t sv[7] = {k_, n_grad, n_prox, n_bt, n_halv, n_fused, n_skips};
         const unsigned long long sv_pseq = ctx->pseq;
+        auto restore = [&]() {
+            k_ = sv[0]; n_grad = sv[1]; n_prox = sv[2]; n_bt = sv[3]; n_halv = sv[4]; n_fused = sv[5]; n_skips = sv[6];
+            gx_valid = false; gz_valid = false;
+        };
         try {
-            step_impl();
-        } catch (const GateTimeout&) {
-            // (several ranks: the others have taken this rank's stale scalars for good ones — not recoverable here)
-            if (ctx->nranks > 1) throw;
-            gate_abort();              // (the pass launched early for the iteration after this one)
-            BZ_HIP(hipStreamSynchronize(cur_));
-            cur_ = ctx->stream;
-            *ptimeout_ = 0;
-            k_ = sv[0]; n_grad = sv[1]; n_prox = sv[2]; n_bt = sv[3]; n_halv = sv[4]; n_fused = sv[5]; n_skips = sv[6];
-            gx_valid = false; gz_valid = false;
-            gate_broken_ = true; gate_env_ = 0; ++n_gate_fallbacks_;
-            std::fprintf(stderr, "Warning: a pre-launched pass timed out at its gate (is the GPU shared?); gated pre-launch is off for this problem\n");
-            step_impl();
-        } catch (const PersistTimeout&) {
-            BZ_HIP(hipStreamSynchronize(ctx->stream));
-            *ptimeout_ = 0;
-            BZ_HIP(hipMemsetAsync(pcounter_.p, 0, PSHARDS * PSHARD_STRIDE * sizeof(unsigned long long), ctx->stream));
-            BZ_HIP(hipMemsetAsync(pgflag_.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-            BZ_HIP(hipStreamSynchronize(ctx->stream));
-            pbase = 0; ctx->pseq = sv_pseq;
-            k_ = sv[0]; n_grad = sv[1]; n_prox = sv[2]; n_bt = sv[3]; n_halv = sv[4]; n_fused = sv[5]; n_skips = sv[6];
-            gx_valid = false; gz_valid = false;
-            persist_ok = false; persist_broken_ = true; ++n_persist_fallbacks_;
-            std::fprintf(stderr, "Warning: persistent two-loop kernel timed out at its grid barrier; using the kernel chain\n");
-            step_impl();
+            try {
+                step_impl();
+            } catch (const GateTimeout&) {
+                // (several ranks: the others have taken this rank's stale scalars for good ones — not recoverable here)
+                if (ctx->nranks > 1) throw;
+                gate_abort();              // (the pass launched early for the iteration after this one)
+                BZ_HIP(hipStreamSynchronize(cur_));
+                cur_ = ctx->stream;
+                *ptimeout_ = 0;
+                restore();
+                gate_broken_ = true; gate_env_ = 0; ++n_gate_fallbacks_;
+                std::fprintf(stderr, "Warning: a pre-launched pass timed out at its gate (is the GPU shared?); gated pre-launch is off for this problem\n");
+                step_impl();
+            } catch (const PersistTimeout&) {
+                if (!persist_ok) throw;
+                BZ_HIP(hipStreamSynchronize(ctx->stream));
+                *ptimeout_ = 0;
+                BZ_HIP(hipMemsetAsync(pcounter_.p, 0, PSHARDS * PSHARD_STRIDE * sizeof(unsigned long long), ctx->stream));
+                BZ_HIP(hipMemsetAsync(pgflag_.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+                BZ_HIP(hipStreamSynchronize(ctx->stream));
+                pbase = 0; ctx->pseq = sv_pseq;
+                restore();
+                persist_ok = false; persist_broken_ = true; ++n_persist_fallbacks_;
+                std::fprintf(stderr, "Warning: persistent two-loop kernel timed out at its grid barrier; using the kernel chain\n");
+                step_impl();
+            }
+        } catch (...) {
+            more_coming_ = false;
+            try { gate_quiesce(); } catch (...) {}
+            throw;
         }
+        if (!more_coming_) gate_quiesce();
     }
     int64_t n_persist_fallbacks_ = 0;
    private:
@@ -2348,7 +2381,7 @@ template <class T> class Solver final : public SolverBase {
             // non-temporal loads/stores once the working set (2M + 11 vectors) no longer fits the 256 MB Infinity
             // Cache.  Measured fused-pass times, default policy vs non-temporal: n = 1.25e6 (210 MB) 39.0 / 44.5 us,
             // 1.8e6 (302 MB) 51.0 / 60.4, 2.5e6 (420 MB) 90.1 / 81.5, 5e6 (840 MB) 171 / 159, 1e7 322 / 314.
-            static const int nt_env = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
+            const int nt_env = nt_env_;      // (BZ_NT, read at every bz_panoc_begin: the tests run both instantiations)
             // headline family with everything uniform fixed at compile time (see the kernel)
             static const int spec_env = std::getenv("BZ_SPEC") ? std::atoi(std::getenv("BZ_SPEC")) : 1;
             const int fam = fused_family();
@@ -2362,7 +2395,9 @@ template <class T> class Solver final : public SolverBase {
             // re-materialise it afterwards with two generic kernels (the same bits either way)
             // ... and during the first 20 iterations of a solve: ALPS subproblems are often that short (13 of them
             // with 180 inner iterations in all on cfg 2), and a stored z costs a tenth of re-materialising one
-            const bool near_stop = (double)stop_norm_ <= 10.0 * opt.tol || k_ <= 20;
+            // (tol = 0: the caller has said the solve never stops by itself — bench.py's timed region, the step-wise parity
+            // tests — so no early stop is being prepared for; whoever asks for z gets it re-materialised, same bits)
+            const bool near_stop = (double)stop_norm_ <= 10.0 * opt.tol || (k_ <= 20 && opt.tol > 0.0);
             T* const zstore = (skipz_env_ && !near_stop) ? (T*)nullptr : Z_[zn].p;
             z_skipped = zstore == nullptr;
             static const int off32_env = std::getenv("BZ_OFF32") ? std::atoi(std::getenv("BZ_OFF32")) : 1;

@@ -140,7 +140,7 @@ class Problem:
             err = self._keep[-1][0]
             del self._keep[-1][:]
             from .oracles import CallbackError
-            raise CallbackError(f"oracle callback raised {type(err).__name__}: {err}") from err
+            raise CallbackError(f"oracle callback raised {type(err).__name__}: {err}") from err      # (rc is BZ_ERR_CALLBACK)
         L.check(rc)
 
     def _in(self, a, n):

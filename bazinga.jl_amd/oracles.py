@@ -404,10 +404,16 @@ def lower_generic(f, g, c, D, n, ny, dtype, slack=False):
 
     def guard(fn, default):
         def wrapped(*a):
+            if errors:                      # an earlier callback of this library call failed: evaluate nothing more
+                L.load().bz_callback_abort()
+                return default
             try:
                 return fn(*a)
             except BaseException as e:      # noqa: BLE001  (nothing may unwind through the C frames)
                 errors.append(e)
+                # the library call in progress ends with BZ_ERR_CALLBACK as soon as this callback has returned
+                # (device.Problem._call then raises CallbackError from the parked exception)
+                L.load().bz_callback_abort()
                 return default
         return wrapped
 

@@ -51,7 +51,9 @@ def lib_sources_sha():
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "bazinga.jl_amd", "csrc", "*.h")) +
                    glob.glob(os.path.join(ROOT, "bazinga.jl_amd", "csrc", "*.hip")) +
-                   [os.path.join(ROOT, "include", "bazinga_hip.h")])
+                   glob.glob(os.path.join(ROOT, "bazinga.jl_amd", "csrc", "*.inc")) +      # (the family instantiations)
+                   [os.path.join(ROOT, "bazinga.jl_amd", "csrc", "Makefile"),               # (the compiler flags)
+                    os.path.join(ROOT, "include", "bazinga_hip.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
@@ -99,11 +101,24 @@ def roofline_of(prof, cats, workload, n, steps):
            "avg_launch_us": round(avg_s * 1e6, 3), "timed_launches": r["timed_launches"],
            "launches_per_iteration": round(r["launches"] / max(1, steps), 3),
            "moved_bytes_per_launch": int(per_launch),
+           # (how many n-vectors one launch of this kernel streams: 9 = the m + 1 iterates, q, b in and x_d out; 10 / 11 with
+           # mu*y / mu streamed, +1 whenever z is stored — comparable across windows of any K)
+           "streams_per_launch": round(per_launch / (n * 8.0), 3) if workload.startswith(("cfg2", "cfg5")) else None,
            "frac_of_copy_ceiling": round(achieved / COPY_CEILING_GBS, 4),
            "traffic_rate": round(traffic / avg_s / 1e9, 1) if traffic else None,
            "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
            "wasted_traffic_ratio": round(traffic / per_launch, 4) if traffic else None}
     return out, moved_iter
+
+
+def roofline_note(roof, ms_per_step):
+    """The launches that carry a start / stop event pair are never pre-launched behind their gate and cost a few microseconds
+    more than the plain ones they stand for: when the evented average of a once-per-iteration kernel exceeds the whole
+    iteration's wall time, say so in the line (the direction is harmless: `frac` is understated)."""
+    if roof and roof.get("launches_per_iteration", 0) >= 0.99 and roof["avg_launch_us"] > 1e3 * ms_per_step:
+        roof["note"] = ("evented launches (avg %.1f us) are slower than the untimed ones they sample: the whole iteration takes "
+                        "%.1f us; `achieved` / `frac` are understated by that margin" % (roof["avg_launch_us"], 1e3 * ms_per_step))
+    return roof
 
 
 def algorithmic_bytes_per_iter(n, w=8, m=M_LBFGS, n_al=2, n_fb=1, p_al=6):
@@ -511,6 +526,7 @@ def side_workload(args):
     its = args.steps / elapsed
     cats = [k for k in prof if k not in ("collect", "all_gather")]
     roof, moved_iter = roofline_of(prof, cats, args.workload, n, args.steps)
+    roofline_note(roof, 1e3 * elapsed / args.steps)
     if args.workload == "cfg4":
         # the two dense products stream the same matrix; the roofline object is the slower of the two, the other
         # one is listed beside it
@@ -551,6 +567,77 @@ def side_workload(args):
     prob.close()
 
 
+def self_launch(n_ranks, argv, worker=None):
+    """`python bench.py --gpus N` started plainly (no launcher: WORLD_SIZE unset): become the launcher.  N child processes,
+    one per GPU, each with the environment torch.distributed.run would give it (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT on 127.0.0.1); rank 0's stdout — the ONE JSON line — is relayed, everybody's stderr is
+    inherited, and the exit code is the first non-zero one (the other ranks are then ended: the exact PIDs started here).
+    Runs before this process has imported the library or made any GPU call.  `worker`: the script the ranks run (this
+    file; tests pass a stub through BZ_BENCH_WORKER)."""
+    import socket
+    import subprocess
+    worker = worker or os.environ.get("BZ_BENCH_WORKER") or os.path.abspath(__file__)
+    with socket.socket() as sk:                       # a free port for the rendezvous (the group tries port + 1 ... + 39)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BZ_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: the mailboxes and RCCL need it on this pool)
+        procs.append(subprocess.Popen([sys.executable, worker] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    note(f"self-launch: {n_ranks} ranks, rendezvous 127.0.0.1:{port}")
+    rc = 0
+    out0 = b""
+    try:
+        import threading
+        buf = []
+        rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+        rd.start()
+        live = set(range(n_ranks))
+        while live and rc == 0:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0:
+                        rc = c
+                        note(f"self-launch: rank {r} exited with code {c}; ending the other ranks")
+                        break
+            time.sleep(0.05)
+        if rc != 0:
+            for r in sorted(live):
+                procs[r].terminate()
+            t_end = time.time() + 15.0
+            for r in sorted(live):
+                try:
+                    procs[r].wait(max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+        rd.join(30.0)
+        out0 = buf[0] if buf else b""
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    if rc == 0 and not any(ln.startswith("{") for ln in out0.decode("utf-8", "replace").splitlines()):
+        note("self-launch: rank 0 printed no JSON line")
+        rc = 3
+    return rc
+
+
+def fail(msg, rank=0, n_gpus=1):
+    """Fail loudly: rank 0 prints a JSON line that says why (never a number for a configuration that was not measured),
+    every rank exits non-zero."""
+    if rank == 0:
+        print(json.dumps({"metric": "PANOC inner iterations/sec", "value": None, "unit": "iterations/s", "n_gpus": n_gpus,
+                          "error": str(msg)[:600]}), flush=True)
+    raise SystemExit(f"[bench] rank {rank}: {msg}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -582,6 +669,10 @@ def main():
                          "the N > 1 path on a one-GPU box, where RCCL refuses two ranks on one device")
     args = ap.parse_args()
 
+    # N > 1 without a launcher: start the N ranks ourselves, BEFORE anything touches the GPU (or loads the library)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.workload in ("cfg2", "cfg5"):
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     import bazinga_jl_amd as bz
 
     tuned = bz.runtime_tuning()      # explicit opt-in (the library no longer sets process-wide variables by itself)
@@ -589,13 +680,16 @@ def main():
     if args.workload == "cfg5":
         n = 100_000_000
     if args.workload in ("cfg3", "cfg4", "als"):
+        if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            fail(f"--workload {args.workload} is a single-GPU line (the sharded forms of cfg 3 / cfg 4 are covered by "
+                 "tests/test_gpu_p2p.py, not benchmarked)", int(os.environ.get("RANK", "0")), args.gpus)
         return side_workload(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with that many ranks "
-                         f"(WORLD_SIZE={world})")
+    if args.gpus != world:
+        # (never time another rank count than the one asked for)
+        fail(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", rank, world)
     grp = None
     comm_id = None
     if world > 1:
@@ -676,63 +770,101 @@ def main():
     # N > 1: scalar exchange through peer-to-peer mailboxes (no collective call; the persistent two-loop
     # kernel runs sharded).  It is taken only if it reproduces the RCCL path's scalars on this node;
     # otherwise the RCCL all-gather path (always correct, slower) is timed.
+    # Gated pre-launch is off by default in the library when there are several ranks: a launch that misses its gate
+    # cannot be redone there.  It is asked for (BZ_GATE=1, read at every bz_panoc_begin) only after the p2p transport WITH
+    # gated launches has reproduced, on this node, the plain launches of the RCCL path (or, without RCCL, the same bits on
+    # every rank) — first with the gate, then without, each attempt on freshly connected mailboxes.
     transport = "none" if world == 1 else ("rccl" if ctx is not None else None)
     p2p_note = None
     ctx_rccl = None
-    if world > 1 and not (args.no_p2p and ctx is not None):
-        ok, ctx2 = 1, None
-        try:                                    # stage 1: map everybody's mailbox
-            ctx2 = bz.Context(device=dev, rank=rank, nranks=world, comm_id=None)
-            h = ctx2.p2p_export()
+    gate = "default" if world == 1 else "0"
+    if world > 1:
+        os.environ["BZ_GATE"] = "0"
+
+    def p2p_context():
+        """a context with everybody's mailbox mapped, or (None, why); the same group operations on every rank"""
+        ok, c2, why = 1, None, None
+        try:
+            c2 = bz.Context(device=dev, rank=rank, nranks=world, comm_id=None)
+            h = c2.p2p_export()
         except Exception as e:      # noqa: BLE001
-            ok, p2p_note = 0, f"p2p export failed: {e!r}"[:300]
+            ok, why = 0, f"p2p export failed: {e!r}"[:300]
             h = b"\0" * 64
         hs = grp.allgather(h)
         dvs = [int(v) for v in grp.allgather(str(dev).encode())]
         if agree(ok):
             try:
-                ctx2.p2p_connect(hs, dvs)
+                c2.p2p_connect(hs, dvs)
             except Exception as e:      # noqa: BLE001
-                ok, p2p_note = 0, f"p2p connect failed: {e!r}"[:300]
+                ok, why = 0, f"p2p connect failed: {e!r}"[:300]
         else:
             ok = 0
-        if agree(ok):                           # stage 2: 8 iterations, same scalars as the RCCL path
-            keys = ("gamma", "f_x", "g_z", "stop_norm", "FBE")
-            sa = None
-            if ctx is not None:
+        if not agree(ok):
+            if c2 is not None:
+                c2.close()
+            return None, why or "p2p setup failed on another rank"
+        return c2, None
+
+    if world > 1 and not (args.no_p2p and ctx is not None):
+        keys = ("gamma", "f_x", "g_z", "stop_norm", "FBE")
+        sa = None
+        if ctx is not None:                     # the reference: the RCCL path, one step per call (plain launches)
+            ok_a = 1
+            try:
                 pa = make_problem(ctx)
-                for _ in range(8):
-                    pa.panoc_step()      # (one step per call: plain launches, the reference for the check below)
+                for _ in range(24):
+                    pa.panoc_step()
                 sa = pa.panoc_scalars()
                 pa.close()
-            sb = None
+            except Exception as e:      # noqa: BLE001
+                ok_a, rccl_note = 0, f"RCCL reference run failed: {e!r}"[:300]
+            if not agree(ok_a):
+                sa = None
+        same_gpu = os.environ.get("BZ_BENCH_SAME_GPU") == "1"
+        notes = []
+        for try_gate in (("0",) if same_gpu else ("1", "0")):
+            ctx2, why = p2p_context()
+            if ctx2 is None:
+                notes.append(why)
+                break                           # (no mailboxes: the gate makes no difference)
+            os.environ["BZ_GATE"] = try_gate
+            ok, sb, why, gated = 1, None, None, 0
             try:
                 pb = make_problem(ctx2)
-                pb.panoc_steps(8)        # (the library's own loop, as in the timed region: gated pre-launch + mailboxes)
+                pb.panoc_steps(24)              # (the library's own loop, as in the timed region: mailboxes (+ gated pre-launch))
                 sb = pb.panoc_scalars()
+                gated = int(pb.panoc_stats().n_gated_launches)
                 pb.close()
                 if sa is not None:
                     for key in keys:
                         if not abs(sa[key] - sb[key]) <= 1e-9 * max(1.0, abs(sa[key])):
-                            ok, p2p_note = 0, f"p2p/rccl mismatch on {key}: {sb[key]} vs {sa[key]}"
+                            ok, why = 0, f"p2p/rccl mismatch on {key}: {sb[key]} vs {sa[key]}"
                 if not all(np.isfinite(sb[key]) for key in keys):
-                    ok, p2p_note = 0, "p2p run produced non-finite scalars"
+                    ok, why = 0, "p2p run produced non-finite scalars"
+                if try_gate == "1" and gated == 0:
+                    ok, why = 0, "no launch went through its gate"
             except Exception as e:      # noqa: BLE001  (a peer never answered: every rank times out alike)
-                ok, p2p_note = 0, f"p2p run failed: {e!r}"[:300]
+                ok, why = 0, f"p2p run failed: {e!r}"[:300]
             # every rank must hold the same bits (they take the line-search decisions independently)
             mine = repr([sb[key] for key in keys]).encode() if sb is not None else b"none"
             if len(set(grp.allgather(mine))) != 1:
-                ok, p2p_note = 0, p2p_note or "ranks disagree on the p2p scalars"
+                ok, why = 0, why or "ranks disagree on the p2p scalars"
             if agree(ok):
                 if ctx is not None:
                     ctx_rccl = ctx
-                ctx, transport = ctx2, "p2p"
+                ctx, transport, gate = ctx2, "p2p", try_gate
                 if sa is None:
-                    p2p_note = "p2p checked for rank agreement only (no RCCL communicator: " + (rccl_note or "--no-rccl") + ")"
-        if transport != "p2p" and p2p_note is None:
-            p2p_note = "p2p rejected on another rank"
+                    notes.append("p2p checked for rank agreement only (no RCCL communicator: " + (rccl_note or "--no-rccl") + ")")
+                break
+            notes.append(("gated launches rejected: " if try_gate == "1" else "p2p rejected: ") + (why or "on another rank"))
+            try:
+                ctx2.close()
+            except Exception:       # noqa: BLE001
+                pass
+        os.environ["BZ_GATE"] = gate if transport == "p2p" else "0"
+        p2p_note = "; ".join(notes) or None
     if ctx is None:
-        raise SystemExit(f"[bench] no working scalar transport at N={world}: {rccl_note}; {p2p_note}")
+        fail(f"no working scalar transport at N={world}: {rccl_note}; {p2p_note}", rank, world)
     def sync(ok=1):
         """Barrier + device drain that carries a health flag: the SAME group operation on every rank whatever
         happened locally, so one rank's failure cannot leave the others waiting in a different collective."""
@@ -818,15 +950,28 @@ def main():
     prob = make_problem(ctx)
     R = timed_run(prob, args.steps, args.warmup)
     note(f"rank {rank}: timed run done" + (f": FAILED {R['failed']}" if "failed" in R else f": {args.steps / R['elapsed']:.1f} it/s"))
-    if "failed" in R and transport == "p2p" and ctx_rccl is not None:
-        # every rank sees the same verdict (sync carries it): fall back to the RCCL transport together
-        p2p_note = f"p2p failed in the timed run ({R['failed']}); RCCL timed instead"
+    if "failed" in R and transport == "p2p" and gate == "1":
+        # every rank sees the same verdict (sync carries it): the same transport on fresh mailboxes, plain launches
+        p2p_note = ((p2p_note + "; ") if p2p_note else "") + f"gated launches failed in the timed run ({R['failed']})"
         print(f"[bench] rank {rank}: {p2p_note}", file=sys.stderr, flush=True)
+        gate = os.environ["BZ_GATE"] = "0"
+        c3, why = p2p_context()
+        if c3 is not None:
+            ctx = c3
+            prob = make_problem(ctx)
+            R = timed_run(prob, args.steps, args.warmup)
+        else:
+            R = {"failed": f"{R['failed']}; then {why}"}
+    if "failed" in R and transport == "p2p" and ctx_rccl is not None:
+        p2p_note = ((p2p_note + "; ") if p2p_note else "") + f"p2p failed in the timed run ({R['failed']}); RCCL timed instead"
+        print(f"[bench] rank {rank}: {p2p_note}", file=sys.stderr, flush=True)
+        gate = os.environ["BZ_GATE"] = "0"
         ctx, transport = ctx_rccl, "rccl"
+        ctx_rccl = None
         prob = make_problem(ctx)
         R = timed_run(prob, args.steps, args.warmup)
     if "failed" in R:
-        raise SystemExit(f"[bench] rank {rank}: timed run failed: {R['failed']}")
+        fail(f"timed run failed: {R['failed']}", rank, world)
     # K-step block shorter than 100 ms: repeat it from a fresh solve (same warm-up; every rank takes the same
     # decision from the max-over-ranks time) and report the spread beside the headline value
     repeats = None
@@ -848,12 +993,15 @@ def main():
     # RCCL all-gather transport is timed as well and printed beside it
     rccl_extra = None
     if world > 1 and transport == "p2p" and ctx_rccl is not None:
+        os.environ["BZ_GATE"] = "0"              # (gated launches were checked on the mailbox transport only)
         pr = make_problem(ctx_rccl)
         ctx_saved, ctx = ctx, ctx_rccl
         Rr = timed_run(pr, args.steps, args.warmup)
         ctx = ctx_saved
         pr.close()
-        rccl_extra = ({"value": round(args.steps / Rr["elapsed"], 3), "ms_per_step": round(1e3 * Rr["elapsed"] / args.steps, 5)}
+        os.environ["BZ_GATE"] = gate
+        rccl_extra = ({"value": round(args.steps / Rr["elapsed"], 3), "ms_per_step": round(1e3 * Rr["elapsed"] / args.steps, 5),
+                       "gated_prelaunch": False}
                       if "failed" not in Rr else {"value": None, "note": Rr["failed"]})
     elapsed, st0, st1, sc, prof_all, prof_warm, dom = (R[k] for k in ("elapsed", "st0", "st1", "sc", "prof", "prof_warm", "dom"))
 
@@ -902,13 +1050,14 @@ def main():
         # k_twoloop_persist 4m passes + k_fused_sep 13)
         prof2 = R["prof2"]
         roof, moved_iter = roofline_of(prof2, ALG, args.workload if headline else args.workload + ":" + args.family, nl, args.steps)
+        roofline_note(roof, 1e3 * elapsed / args.steps)
         # the reference's dataflow: 65 passes per iteration on this workload at m = 5 — a model of
         # what the reference moves, reported as a ratio, never as a roofline fraction
         ref_iter = algorithmic_bytes_per_iter(nl, m=max(1, m), n_al=2, n_fb=1)
         out = {
             "metric": ("PANOC inner iterations/sec, n=10^7 l1-quadratic" if n == 10_000_000 else "PANOC inner iterations/sec, n=%d l1-quadratic" % n)
             + ("" if headline else " (family %s)" % args.family),
-            "value": round(its, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "value": round(its, 3), "unit": "iterations/s", "n_gpus": world, "transport_timed": transport, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
@@ -923,6 +1072,11 @@ def main():
                        ("peer-to-peer mailboxes over xGMI" if transport == "p2p" else "RCCL all-gather"),
                        "scalar_transport": transport, "p2p_note": p2p_note, "rccl_note": rccl_note,
                        "rccl_nranks": rccl_nranks,
+                       "gated_prelaunch": {"default": "library default (on: one rank)", "1": "on (checked against plain launches on this node)",
+                                           "0": "off"}[gate],
+                       "gated_launches_in_timed_region": int(st1.n_gated_launches) - (int(st0.n_gated_launches) if not R.get("restarts") else 0),
+                       "launcher": "self (bench.py --gpus N started its own ranks)" if os.environ.get("BZ_BENCH_SELF_LAUNCHED") else
+                       ("torch.distributed.run / external" if world > 1 else "none"),
                        "lbfgs_form": "compact representation: one pass and one reduction phase per iteration" if compact
                        else "two-loop recursion (persistent kernel, 2M-1 grid phases)",
                        "runtime_tuning": {"applied_mask": tuned, "env": runtime_env()},

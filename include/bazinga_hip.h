@@ -39,6 +39,7 @@ extern "C" {
 #define BZ_ERR_COMM          -5   /* RCCL failure                                     */
 #define BZ_ERR_MU            -6   /* "parameters `mu` must be positive"
                                      (src/utilities/auglagfun.jl:33-34,92-93)        */
+#define BZ_ERR_CALLBACK      -7   /* a generic-oracle callback failed (bz_callback_abort) */
 
 /* ---- numeric type ----------------------------------------------------- */
 #define BZ_F64 0
@@ -98,6 +99,13 @@ typedef void (*bz_c_eval_fn)(void* user, const void* x, void* cx, int64_t n, int
 typedef void (*bz_c_jtprod_fn)(void* user, const void* x, const void* v, void* jtv, int64_t n, int64_t ny);
 /* proj!(s, D, v)                                     demo/rosenbrock.jl:77-80                             */
 typedef void (*bz_D_proj_fn)(void* user, const void* v, void* s, int64_t ny);
+
+/* Error channel of the callbacks (r03).  A callback cannot unwind through the library's C frames: one that failed
+ * (an exception in the host language — the reference's oracles `error(...)` freely, e.g. src/utilities/auglagfun.jl:33)
+ * calls bz_callback_abort() before it returns whatever it has; the library call in progress on this thread then ends
+ * with BZ_ERR_CALLBACK right after that callback, without evaluating anything on the buffers it left behind.  The flag
+ * is per thread and is cleared by every library call that takes a bz_problem.                               */
+void bz_callback_abort(void);
 
 typedef struct bz_ctx     bz_ctx;
 typedef struct bz_problem bz_problem;

@@ -66,6 +66,17 @@ function check(rc::Cint)
     msg = unsafe_string(ccall((:bz_last_error, lib), Cstring, ()))
     error(msg)                       # same ErrorException the reference throws (auglagfun.jl:33-34)
 end
+# library calls on a problem whose oracles are callbacks: an exception parked by a callback (BZ_ERR_CALLBACK) is rethrown
+# as it was raised — the caller sees what the reference's own `gradient!` / `prox!` / `eval!` would have thrown
+function check(rc::Cint, p)
+    box = p.keep isa Tuple ? p.keep[end] : nothing
+    if box !== nothing && box[].err !== nothing
+        e = box[].err
+        box[].err = nothing
+        throw(e)
+    end
+    check(rc)
+end
 
 const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
 function context()
@@ -166,31 +177,54 @@ lower_D!(d, D) = :generic
 # the package's protocol (src/Bazinga.jl:11-16) — is handed to the library as @cfunction callbacks.  The host
 # evaluates f / grad f, prox_g, c, J'v and proj_D; the L-BFGS and line-search vector work stays on the device.
 # When one of the four is generic, all four travel as callbacks (the structured types have the protocol anyway).
-struct GenericOracles{F,G,C,DD,T}
+mutable struct GenericOracles{F,G,C,DD,T}
     f::F; g::G; c::C; D::DD
+    err::Any                     # an exception raised inside a callback, parked until the library call has returned
+end
+# A callback cannot unwind through the library's C frames: it parks the exception and asks the library to end the call
+# in progress (bz_callback_abort -> BZ_ERR_CALLBACK); `check_generic` rethrows it on the Julia side.
+function _cb_guard(body, o, default)
+    o.err === nothing || (ccall((:bz_callback_abort, lib), Cvoid, ()); return default)
+    try
+        return body()
+    catch e
+        o.err = e
+        ccall((:bz_callback_abort, lib), Cvoid, ())
+        return default
+    end
 end
 function _cb_f(u::Ptr{Cvoid}, x::Ptr{T}, dfx::Ptr{T}, n::Int64)::Float64 where {T}
     o = unsafe_pointer_to_objref(u)
-    Float64(Bazinga.gradient!(unsafe_wrap(Array, dfx, n), o.f, unsafe_wrap(Array, x, n)))
+    _cb_guard(o, NaN) do
+        Float64(Bazinga.gradient!(unsafe_wrap(Array, dfx, n), o.f, unsafe_wrap(Array, x, n)))
+    end
 end
 function _cb_g(u::Ptr{Cvoid}, x::Ptr{T}, gamma::Float64, z::Ptr{T}, n::Int64)::Float64 where {T}
     o = unsafe_pointer_to_objref(u)
-    Float64(Bazinga.prox!(unsafe_wrap(Array, z, n), o.g, unsafe_wrap(Array, x, n), T(gamma)))
+    _cb_guard(o, NaN) do
+        Float64(Bazinga.prox!(unsafe_wrap(Array, z, n), o.g, unsafe_wrap(Array, x, n), T(gamma)))
+    end
 end
 function _cb_ceval(u::Ptr{Cvoid}, x::Ptr{T}, cx::Ptr{T}, n::Int64, ny::Int64)::Cvoid where {T}
     o = unsafe_pointer_to_objref(u)
-    Bazinga.eval!(unsafe_wrap(Array, cx, ny), o.c, unsafe_wrap(Array, x, n)); nothing
+    _cb_guard(o, nothing) do
+        Bazinga.eval!(unsafe_wrap(Array, cx, ny), o.c, unsafe_wrap(Array, x, n)); nothing
+    end
 end
 function _cb_cjt(u::Ptr{Cvoid}, x::Ptr{T}, v::Ptr{T}, jtv::Ptr{T}, n::Int64, ny::Int64)::Cvoid where {T}
     o = unsafe_pointer_to_objref(u)
-    Bazinga.jtprod!(unsafe_wrap(Array, jtv, n), o.c, unsafe_wrap(Array, x, n), unsafe_wrap(Array, v, ny)); nothing
+    _cb_guard(o, nothing) do
+        Bazinga.jtprod!(unsafe_wrap(Array, jtv, n), o.c, unsafe_wrap(Array, x, n), unsafe_wrap(Array, v, ny)); nothing
+    end
 end
 function _cb_D(u::Ptr{Cvoid}, v::Ptr{T}, s::Ptr{T}, ny::Int64)::Cvoid where {T}
     o = unsafe_pointer_to_objref(u)
-    Bazinga.proj!(unsafe_wrap(Array, s, ny), o.D, unsafe_wrap(Array, v, ny)); nothing
+    _cb_guard(o, nothing) do
+        Bazinga.proj!(unsafe_wrap(Array, s, ny), o.D, unsafe_wrap(Array, v, ny)); nothing
+    end
 end
 function lower_generic!(d, f, g, c, D, ::Type{T}) where {T}
-    box = Ref(GenericOracles{typeof(f),typeof(g),typeof(c),typeof(D),T}(f, g, c, D))     # rooted by the Problem
+    box = Ref(GenericOracles{typeof(f),typeof(g),typeof(c),typeof(D),T}(f, g, c, D, nothing))     # rooted by the Problem
     d.f_kind = 5; d.g_kind = 8; d.c_kind = 2; d.D_kind = 7
     d.cb_user = pointer_from_objref(box[])
     d.cb_f_gradient = @cfunction(_cb_f, Float64, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Int64))
@@ -241,10 +275,10 @@ const _problems = WeakKeyDict{Any,Problem}()
 function (s::PANOCplusHIP)(; f::Bazinga.AugLagFun, g::Bazinga.NonsmoothCostFun, x0::AbstractVector{T}) where {T}
     p = get!(() -> Problem(f.f, g.g, f.c, f.D, length(x0), length(f.y), T), _problems, f)
     mu = convert(Vector{T}, f.mu); y = convert(Vector{T}, f.y)
-    check(ccall((:bz_problem_set_multipliers, lib), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), p.h, mu, y))
+    check(ccall((:bz_problem_set_multipliers, lib), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), p.h, mu, y), p)
     x = similar(x0); st = Ref(PanocStats())
     check(ccall((:bz_panoc_solve, lib), Cint, (Ptr{Cvoid}, Ref{PanocOpts}, Ptr{T}, Ptr{T}, Ref{PanocStats}),
-                p.h, Ref(s.opts), x0, x, st))
+                p.h, Ref(s.opts), x0, x, st), p)
     f.fx = T(st[].f_z)          # side channels alps reads back (alps.jl:68)
     g.gz = T(st[].g_z)
     g.gamma = st[].gamma
@@ -269,7 +303,7 @@ function alps(f, g, c, D, x0::AbstractVector{T}, y0::AbstractVector{T}; tol::Rea
     x = similar(x0); y = similar(y0); s = similar(y0); mu = similar(y0); st = Ref(AlpsStats())
     check(ccall((:bz_alps_solve, lib), Cint,
                 (Ptr{Cvoid}, Ref{AlpsOpts}, Ref{PanocOpts}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{AlpsStats}),
-                p.h, Ref(ao), Ref(po), x0, y0, x, y, s, mu, st))
+                p.h, Ref(ao), Ref(po), x0, y0, x, y, s, mu, st), p)
     r = st[]
     return x, y, Int(r.tot_it), Int(r.tot_inner_it), r.elapsed_s, _status[r.status + 1], T(r.inner_tol),
            (r.tot_it == 0 ? nothing : T(r.norm_res_prim)), s, mu      # alps.jl:34,115: `nothing` before the first outer iteration

@@ -193,3 +193,32 @@ def test_als_with_compact_lbfgs_and_no_acceleration(bz, ref):
     a2 = bz.als(*dev, x0, y0, subsolver=lambda **kw: bz.PANOCplus(directions=bz.NoAcceleration(), **kw), resident=True)
     assert a2[5] == o2[5] and a2[2] == o2[2] and abs(a2[3] - o2[3]) <= max(3, 0.1 * o2[3])
     assert rel(a2[0], o2[0]) <= 1e-6
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("g,D", [("l1", "box"), ("l1", "free"), ("zero", "box")])
+def test_als_with_zero_smooth_cost_terminates_like_the_reference(bz, ref, g, D):
+    """f = Zero in the slack form: grad F(xs + 1) = grad F(xs), so `lower_bound_smoothness_constant` is 0 and gamma = alpha / 0 =
+    inf.  The reference's step-size loop compares NaNs there and leaves; its solve then runs on NaN iterates to the subsolver's
+    iteration cap and `als` ends with :exception, or :max_iter when the objective stays a number (als.jl:68-72,96-110).  The
+    device loop once halved the infinite gamma for ever (a hang, fixed in r02 `71ac09b` with no test: VERDICT r02 item 1(d)):
+    it must terminate, with the oracle's status and counts."""
+    import warnings
+    n = 400
+    rng = np.random.default_rng(11)
+    x0, y0 = 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(n)
+    g_d, g_r = (bz.NormL1(0.5), ref.NormL1(0.5)) if g == "l1" else (bz.Zero(), ref.Zero())
+    D_d, D_r = ((bz.ClosedSet(bz.IndBox(-0.5, 0.7)), ref.ClosedSet(ref.IndBox(-0.5, 0.7))) if D == "box"
+                else (bz.FreeSet(), ref.FreeSet()))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = ref.als(ref.Zero(), g_r, ref.IdentityFunction(), D_r, x0, y0, maxit=4)
+    a = bz.als(bz.Zero(), g_d, bz.IdentityFunction(), D_d, x0, y0, maxit=4)
+    assert o[5] in ("exception", "max_iter")
+    assert a[5] == o[5] and a[2] == o[2] and a[3] == o[3], (a[5], a[2], a[3], o[5], o[2], o[3])
+    # ... and a single inner solve started there stops at its iteration cap instead of spinning
+    prob = bz.Problem(bz.Zero(), g_d, bz.IdentityFunction(), D_d, n, n, np.float64, slack=True)
+    prob.set_multipliers(np.full(n, 0.1), y0)
+    z, st = prob.panoc_solve(bz.PANOCplus(tol=1e-8, maxit=50).c_opts(), np.concatenate([x0, x0]))
+    assert st.iters == 50 and not np.isfinite(st.gamma)
+    prob.close()

@@ -5,10 +5,14 @@ and grad L(.) are affine maps, so their values at the trial point x + d follow f
 (the linear combination that forms d) with no pass over A; a pass-over-A evaluation every `affine_refresh`-th iteration
 bounds the rounding drift.  An iteration then reads A twice (the gradient at z) instead of four times.  Accepted only
 because the iterates stay inside the oracle's own rounding envelope, fp64 and fp32, over 30 states — checked here."""
+import os
+
 import numpy as np
 import pytest
 
 from tests.test_gpu_parity import make_cfg4, rel, run_traces
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -90,19 +94,37 @@ def test_affine_images_with_diag_quadratic_f_and_free_set(bz, ref):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("refresh", [8, 0])
-def test_dense_full_size_iterates_fp32(bz, ref, refresh):
-    """BASELINE config 4 at full size (A 8192 x 65536 fp32 = 2 GiB): 8 PANOCplus states against the numpy oracle in
-    fp32, the MFMA transposed product in the loop — with the affine images (default) and with
-    every gradient evaluated by passes over A."""
+@pytest.mark.parametrize("refresh,states", [(16, 22), (8, 8), (0, 8)])
+def test_dense_full_size_iterates_fp32(bz, ref, refresh, states):
+    """BASELINE config 4 at full size (A 8192 x 65536 fp32 = 2 GiB) against the numpy oracle in fp32, the MFMA
+    transposed product in the loop: at the SHIPPED default affine_refresh = 16 — what `bench.py --workload cfg4` times —
+    for 22 states, so that a pass-over-A refresh of the images is crossed (iteration 16) and five more iterations run on
+    the refreshed images (demo/basispursuit.jl:38-49,62-66); with refresh 8 and with every
+    gradient evaluated by passes over A for 8 states.
+
+    The tolerance is an envelope around the oracle's own rounding sensitivity (its twin with long-double reductions),
+    so the sensitivity itself is bounded here: an envelope that scales with the oracle's noise must not be able to
+    swallow a drift of the images."""
     ny, n = 8192, 65536
     d, dev, orc = full_size_cfg4(bz, ref)
     mu, y, x0 = np.full(ny, 0.1, np.float32), np.zeros(ny, np.float32), np.zeros(n, np.float32)
-    prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 8, minimum_gamma=float(np.finfo(np.float32).eps),
+    prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, states, minimum_gamma=float(np.finfo(np.float32).eps),
                                 dtype=np.float32, ny=ny, affine_refresh=refresh)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"cfg4_full_rows_refresh{refresh}.log"), "w") as fh:
+        for r in rows:
+            fh.write("k=%d ex=%.3e ez=%.3e gamma_dev=%.9g gamma_ref=%.9g stop_dev=%.4e stop_ref=%.4e fused=%d sens=%.3e\n" % tuple(r))
     for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
+        assert sens <= 1e-4, (k, sens)
         assert abs(g_d - g_r) <= 1e-4 * g_r, (k, g_d, g_r)
         assert ex <= max(2e-4, 100 * sens) and ez <= max(2e-4, 100 * sens), (k, ex, ez, sens)
+    stats = prob.panoc_stats()
+    if refresh:
+        # every iteration but the refreshes (and wherever a step-size test failed on images) ran on images
+        its = states - 1
+        assert its - its // refresh - 4 <= stats.n_affine_images <= its
+    else:
+        assert stats.n_affine_images == 0
     prob.profile_reset()
     prob.profile_enable(True)
     prob.panoc_steps(4)

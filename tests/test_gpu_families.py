@@ -9,6 +9,7 @@ bz_families_dk*.hip).  For every family
 Oracle kinds: src/proxoperators/{normL1Box,normL1Nonneg,zero}.jl, ProximalOperators NormL1 / IndBox,
 src/projections/{zeroSet,freeSet,indicatorSet,vanishingConstraints,complementarityConstraints,orConstraints}.jl."""
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -40,7 +41,7 @@ FAMILIES = [
 def make_family(bz, ref, n, fam, dtype=np.float64):
     f, g, D = fam
     d = bz.synth.l1_quadratic(n, dtype=dtype)
-    rng = np.random.default_rng(abs(hash(fam)) % (2 ** 31))
+    rng = np.random.default_rng(zlib.crc32("-".join(fam).encode()))      # (hash() of a str is salted per process)
     scale = 0.2 if D in ("vc", "cc", "eitheror", "xor") else 1.0
     out = []
     for m in (bz, ref):
@@ -82,7 +83,7 @@ def make_family(bz, ref, n, fam, dtype=np.float64):
 
 
 def _run(bz, dev, n, mu, y, x0, iters, env, dtype=np.float64, fuse=True, compact=None):
-    keys = ("BZ_XR", "BZ_UNI", "BZ_GFC", "BZ_GRID", "BZ_TRIALFUSE", "BZ_FAMRT", "BZ_SKIPZ")
+    keys = ("BZ_XR", "BZ_UNI", "BZ_GFC", "BZ_GRID", "BZ_TRIALFUSE", "BZ_FAMRT", "BZ_SKIPZ", "BZ_NT")
     old = {k: os.environ.get(k) for k in keys}
     try:
         for k in keys:
@@ -114,12 +115,22 @@ def _run(bz, dev, n, mu, y, x0, iters, env, dtype=np.float64, fuse=True, compact
 SCALARS = ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "FBE")
 
 
+# The family table holds TWO instantiations per family: default-policy and non-temporal streams (NT = 1), the latter
+# selected by size (n * sizeof(T) * streams > 340e6: every `bench.py --family` line at n = 1e7 times it).  BZ_NT is read
+# at every bz_panoc_begin, so the tests below run each family through both ("half of the family kernel table
+# is never compared with anything").
+NT_FORMS = ["by-size", "nt"]
+
+
+@pytest.mark.parametrize("nt", NT_FORMS)
 @pytest.mark.parametrize("fam", FAMILIES, ids=["-".join(f) for f in FAMILIES])
-def test_family_forms_are_bitwise_neutral(bz, ref, fam):
+def test_family_forms_are_bitwise_neutral(bz, ref, fam, nt):
     n = 60_010
     dev, orc, mu, y, x0 = make_family(bz, ref, n, fam)
     iters = 70
     pin = {"BZ_GFC": "2", "BZ_GRID": "512", "BZ_TRIALFUSE": "0"}      # one summation tree for every form
+    if nt == "nt":
+        pin["BZ_NT"] = "1"
     base = _run(bz, dev, n, mu, y, x0, iters, dict(pin, BZ_XR="0"))
     # stored-pair form, fused throughout but for the iterations with a tau backtrack or a gamma halving
     assert base[5] == 0 and base[4][3] >= iters - 12 - base[4][0] - base[4][1]
@@ -133,6 +144,7 @@ def test_family_forms_are_bitwise_neutral(bz, ref, fam):
         assert r[5] >= max(4, iters - 12 - 6 * base[4][2] - 2 * base[4][0] - base[4][1]), (env, r[5], base[4])
         if fam != ("diag", "l1", "box") or env.get("BZ_FAMRT"):
             assert "FAM=" in r[6], r[6]                                     # ... in its family instantiation
+        assert ("NT=1" in r[6]) == (nt == "nt"), r[6]                      # ... with the streams the case asks for
         for a, b in zip(r[:3], base[:3]):
             assert np.array_equal(a, b), env
         for key in SCALARS:
@@ -152,12 +164,16 @@ def test_family_forms_are_bitwise_neutral(bz, ref, fam):
     assert np.max(np.abs(g[1] - f[1])) <= 1e-11 * max(1.0, np.max(np.abs(f[1])))
 
 
+@pytest.mark.parametrize("nt", NT_FORMS)
 @pytest.mark.parametrize("fam", FAMILIES, ids=["-".join(f) for f in FAMILIES])
-def test_family_iterates_match_oracle(bz, ref, fam):
+def test_family_iterates_match_oracle(bz, ref, fam, nt, monkeypatch):
     n = 20_010
     dev, orc, mu, y, x0 = make_family(bz, ref, n, fam)
+    if nt == "nt":
+        monkeypatch.setenv("BZ_NT", "1")
     prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, 30, minimum_gamma=float(np.finfo(float).eps))
-    p = prob.profile2() if False else None
+    form = prob.profile2()["k_fused_iterates"]["form"]
+    assert form.startswith("k_fused_compact<XR=2") and ("NT=1" in form) == (nt == "nt"), form
     for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
         assert abs(g_d - g_r) <= 1e-13 * g_r, f"gamma differs at k={k}"
         tol = iter_tol(sens)
@@ -173,14 +189,17 @@ def test_family_iterates_match_oracle(bz, ref, fam):
 
 @pytest.mark.parametrize("fam", [("diag", "l1box", "box"), ("diag", "l1", "xor"), ("zero", "indbox_vec", "boxvec")],
                          ids=["l1box-box", "l1-xor", "indboxvec-boxvec"])
-def test_family_kernels_float32(bz, ref, fam):
+@pytest.mark.parametrize("nt", NT_FORMS)
+def test_family_kernels_float32(bz, ref, fam, nt):
     """fp32 packs hold four elements (two pairs): same neutrality, ragged last chunk included (n % 4 == 2)."""
     n = 50_002
     dev, orc, mu, y, x0 = make_family(bz, ref, n, fam, dtype=np.float32)
     pin = {"BZ_GFC": "2", "BZ_GRID": "512", "BZ_TRIALFUSE": "0"}
+    if nt == "nt":
+        pin["BZ_NT"] = "1"
     base = _run(bz, dev, n, mu, y, x0, 40, dict(pin, BZ_XR="0"), dtype=np.float32)
     r = _run(bz, dev, n, mu, y, x0, 40, dict(pin, BZ_XR="2"), dtype=np.float32)
-    assert base[5] == 0 and r[5] >= 5 and "FAM=" in r[6]
+    assert base[5] == 0 and r[5] >= 5 and "FAM=" in r[6] and ("NT=1" in r[6]) == (nt == "nt")
     for a, b in zip(r[:3], base[:3]):
         assert np.array_equal(a, b)
     for key in SCALARS:

@@ -133,6 +133,46 @@ def test_callback_exception_surfaces_as_python_error(bz):
     assert isinstance(ei.value.__cause__, ZeroDivisionError)
 
 
+def test_failed_callback_ends_the_library_call_at_once(bz):
+    """The error channel of the callbacks (bz_callback_abort, include/bazinga_hip.h): a callback that raises parks its
+    exception and asks the library to end the call in progress.  Nothing more is evaluated — no further callback is invoked,
+    the solve does not iterate on the stale buffers the failed callback left (it used to go on until the
+    objective turned NaN, calling the failing callback again and again)."""
+    calls = {"f": 0, "c": 0, "after": 0}
+    state = {"failed": False}
+
+    class F:
+        def gradient(self, dfx, x):
+            calls["f"] += 1
+            calls["after"] += state["failed"]
+            dfx[...] = x - 1.0
+            return 0.5 * float(np.sum((x - 1.0) ** 2))
+
+    class Cmap:
+        def eval(self, cx, x):
+            calls["c"] += 1
+            calls["after"] += state["failed"]
+            if calls["c"] == 7:
+                state["failed"] = True
+                raise KeyError("seventh eval")
+            cx[...] = x
+
+        def jtprod(self, jtv, x, v):
+            calls["after"] += state["failed"]
+            jtv[...] = v
+
+    n = 6
+    with pytest.raises(bz.CallbackError) as ei:
+        bz.alps(F(), bz.NormL1(0.1), Cmap(), bz.ClosedSet(bz.IndBox(-0.5, 0.5)), np.zeros(n), np.zeros(n))
+    assert isinstance(ei.value.__cause__, KeyError)
+    assert calls["c"] == 7 and calls["after"] == 0
+    # the library is usable afterwards (the abort request does not outlive the call it ended)
+    state["failed"] = False
+    calls["c"] = 100
+    out = bz.alps(F(), bz.NormL1(0.1), Cmap(), bz.ClosedSet(bz.IndBox(-0.5, 0.5)), np.zeros(n), np.zeros(n))
+    assert out[5] == "first_order"
+
+
 def test_object_without_the_protocol_is_rejected(bz):
     with pytest.raises(bz.UnsupportedOracle):
         bz.Problem(object(), bz.NormL1(0.1), bz.IdentityFunction(), bz.FreeSet(), 4, 4, np.float64)

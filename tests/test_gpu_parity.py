@@ -1494,12 +1494,15 @@ def test_shared_device_context_does_not_gate(bz, ref):
     assert outs[0][1].n_gated_launches >= 20 and outs[1][1].n_gated_launches == 0
 
 
-def test_gate_timeout_falls_back_to_plain_launches(bz, ref, monkeypatch):
+@pytest.mark.parametrize("n,persist", [(300_007, True), (100_000, True), (300_007, False)],
+                         ids=["persist-capable", "below-the-persistent-size", "persist-off"])
+def test_gate_timeout_falls_back_to_plain_launches(bz, ref, monkeypatch, n, persist):
     """A pre-launched pass that is not released in time (a stalled host thread; another tenant on the GPU keeping its
     first workgroup from becoming resident) leaves as a whole, the host redoes the iteration with a plain launch and keeps
     the gate off for the problem: the same bits as a solve that never used the gate, one fall-back in the statistics.
-    (BZ_TEST_GATE_TIMEOUT=k: the k-th release is withheld; BZ_GATE_SPIN shortens the poll bounds from ~3 s.)"""
-    n = 300_007
+    (BZ_TEST_GATE_TIMEOUT=k: the k-th release is withheld; BZ_GATE_SPIN shortens the poll bounds from ~3 s.)
+    The gate does not depend on the persistent two-loop kernel being available, nor does its fall-back (the
+    redo used to exist only where that kernel was — n >= BZ_PERSIST_MIN_N = 300000 and `persist` on)."""
     d, dev, orc = make_cfg2(bz, ref, n)
     mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
     runs = []
@@ -1509,13 +1512,13 @@ def test_gate_timeout_falls_back_to_plain_launches(bz, ref, monkeypatch):
         monkeypatch.setenv("BZ_GATE_SPIN", "20000")
         prob = bz.Problem(*dev, n, n, np.float64)
         prob.set_multipliers(mu, y)
-        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), x0)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist).c_opts(), x0)
         prob.panoc_steps(40)
         st = prob.panoc_stats()
         runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(), st))
         # the gate stays off for later solves on this problem
         monkeypatch.setenv("BZ_TEST_GATE_TIMEOUT", "0")
-        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9).c_opts(), x0)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, persist=persist).c_opts(), x0)
         prob.panoc_steps(10)
         runs[-1] += (prob.panoc_stats(),)
         prob.close()
@@ -1526,3 +1529,66 @@ def test_gate_timeout_falls_back_to_plain_launches(bz, ref, monkeypatch):
     assert a[3].n_gate_fallbacks == 0 and b[3].n_gate_fallbacks == 1
     assert 1 <= b[3].n_gated_launches <= 10 and a[3].n_grad == b[3].n_grad
     assert b[4].n_gated_launches == 0
+
+
+def test_gate_timeout_inside_a_whole_solve(bz, ref, monkeypatch):
+    """... and the same inside the solver's own loop (bz_alps_solve -> run_to_completion): the solve ends where the ungated one
+    does, with one fall-back, and nothing is left pre-launched when the call returns (the next call on the problem works)."""
+    n = 60_000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    monkeypatch.setenv("BZ_GATE_SPIN", "20000")
+    outs = []
+    for gate, sab in (("0", "0"), ("1", "12")):
+        monkeypatch.setenv("BZ_GATE", gate)
+        monkeypatch.setenv("BZ_TEST_GATE_TIMEOUT", sab)
+        prob = bz.Problem(*dev, n, n, np.float64)
+        outs.append(bz.alps(*dev, np.zeros(n), np.zeros(n), problem=prob))
+        monkeypatch.setenv("BZ_TEST_GATE_TIMEOUT", "0")
+        prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
+        z, st = prob.panoc_solve(bz.PANOCplus(tol=1e-6).c_opts(), np.zeros(n))
+        outs[-1] += (z, st)
+        prob.close()
+    a, b = outs
+    assert a[5] == b[5] == "first_order" and a[2] == b[2] and a[3] == b[3]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[10], b[10]) and a[11].iters == b[11].iters
+    assert a[11].n_gate_fallbacks == 0 and b[11].n_gate_fallbacks == 1 and b[11].n_gated_launches == 0
+
+
+@pytest.mark.timeout(900)
+def test_headline_size_library_loop_equals_single_steps_bitwise(bz, ref):
+    """What bench.py TIMES against what the 30-state oracle tests STEP, at the benchmark size:
+    bz_panoc_steps (the library runs the loop: the next pass pre-launched behind its gate, z not stored after the first
+    20 iterations and re-materialised on demand, the non-temporal NT = 1 instantiation that n = 1e7 selects) and the same
+    number of bz_panoc_step calls with x and z read after each (plain launches, z forced every state): the same bits in
+    x, z, res and every scalar."""
+    n = 10_000_000
+    d, dev, orc = make_cfg2(bz, ref, n)
+    mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
+    mg = float(np.finfo(float).eps)
+    iters = 45
+    runs = []
+    for mode in ("steps", "single"):
+        prob = bz.Problem(*dev, n, n, np.float64)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=mg).c_opts(), x0)
+        if mode == "steps":
+            prob.panoc_steps(iters)
+        else:
+            for _ in range(iters):
+                prob.panoc_step()
+                prob.panoc_vector("z")
+        st = prob.panoc_stats()
+        form = prob.profile2()["k_fused_iterates"]["form"]
+        runs.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars(), st, form))
+        prob.close()
+    a, b = runs
+    assert "NT=1" in a[5] and "NT=1" in b[5], (a[5], b[5])
+    assert a[4].n_gated_launches >= iters - 8 and b[4].n_gated_launches == 0
+    for u, v in zip(a[:3], b[:3]):
+        assert np.array_equal(u, v)
+    for key in ("k", "gamma", "tau", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_mem", "lbfgs_H",
+                "al_z", "f_z", "FBE"):
+        assert a[3][key] == b[3][key], key
+    assert (a[4].n_backtracks, a[4].n_gamma_halvings, a[4].n_lbfgs_skips, a[4].n_grad, a[4].n_prox) == \
+        (b[4].n_backtracks, b[4].n_gamma_halvings, b[4].n_lbfgs_skips, b[4].n_grad, b[4].n_prox)

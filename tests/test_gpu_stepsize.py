@@ -160,3 +160,20 @@ def test_warm_start_saves_gradient_evaluations(bz, ref):
         tot[warm] = grads
     assert [g[0] for g in tot[False]] == [False] * len(tot[False])
     assert [g[0] for g in tot[True]] == [False] + [True] * (len(tot[True]) - 1)
+
+
+@pytest.mark.parametrize("form", ["default", "two-loop"])
+def test_adaptive_false_without_a_step_size_still_backtracks(bz, ref, form):
+    """`PANOCplus(adaptive = false)` with neither `gamma` nor `Lf`: upstream tests `iter.gamma === nothing || iter.adaptive ==
+    true` at both halving sites, so the ESTIMATED step size is still backtracked (the device took `adaptive` alone
+    and never halved).  cfg 2's Lipschitz estimate is 2x optimistic — every solve halves at its start — so the two readings
+    differ from the first state on."""
+    n = 20011
+    d, dev, orc = make_cfg2(bz, ref, n)
+    mu, y, x0 = np.full(n, 0.1), np.zeros(n), np.zeros(n)
+    rows, st, stats = _side_by_side(bz, ref, dev, orc, n, n, mu, y, x0, 25, dict(adaptive=False),
+                                    compact=None if form == "default" else False)
+    assert st.n_gamma_halvings >= 1 and stats.n_gamma_halvings == st.n_gamma_halvings
+    for k, ex, ez, g_d, g_r in rows:
+        assert abs(g_d - g_r) <= 1e-15 * g_r, f"gamma differs at k={k}: {g_d} {g_r}"
+        assert ex <= RTOL_ITER and ez <= RTOL_ITER, f"iterate mismatch at k={k}: {ex} {ez}"

@@ -82,7 +82,8 @@ class PanocStats(C.Structure):
                 ("n_gamma_halvings", C.c_int64), ("n_fused_iters", C.c_int64),
                 ("n_lbfgs_skips", C.c_int64), ("elapsed_s", C.c_double), ("status", C.c_int32),
                 ("persist_fallbacks", C.c_int32), ("n_affine_images", C.c_int64),
-                ("n_gated_launches", C.c_int64), ("n_gate_aborts", C.c_int64), ("n_gate_fallbacks", C.c_int64)]
+                ("n_gated_launches", C.c_int64), ("n_gate_aborts", C.c_int64), ("n_gate_fallbacks", C.c_int64),
+                ("n_dense_onepass", C.c_int64), ("n_dense_fallbacks", C.c_int64)]
 
 
 class AlpsOpts(C.Structure):

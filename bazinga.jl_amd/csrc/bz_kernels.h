@@ -1306,6 +1306,304 @@ static __global__ void __launch_bounds__(64) k_exchange_collect(XCollectArgs b) 
     exchange_collect_one(b, (int)blockIdx.x, (int)threadIdx.x);
 }
 
+// ---------------------------------------------------------------------------
+// K9, ONE pass over A: gradient!(dlx, al, x) with the dense constraint c(x) = A x - b
+// (src/utilities/auglagfun.jl:73-86 with demo/basispursuit.jl:38-49: eval!(cx, c, x) = A x - b ;
+// jtprod!(jtv, c, x, v) = A'v — SURVEY 7 H6).  As two kernels (k_gemv_n, k_gemv_t) the matrix streams from HBM
+// twice per evaluation; here every row is read once: yhat_i = ((a_i.x - b_i + mu_i y_i) - s_i) / mu_i needs the whole
+// row a_i before it can multiply that row again, so the row must stay on chip in between — 256 KB at n = 65536 fp32,
+// half a CU's register file.  A row GROUP is therefore shared by G workgroups (one per CU) that each own a column
+// slice of 512 * KP packs; the slice of x and the slice of the accumulator A'yhat stay in registers for the whole launch,
+// and so does a RING of four tiles of FT = 2 rows x the slice (KP packs per row and lane).
+//
+// Per tile the G workgroups exchange their FT partial products through a small device-memory mailbox in "LL" form (half
+// a value and a 32-bit sequence tag per 8-byte word: a word is valid exactly when its tag matches, no flag, no fence),
+// fold them in slice order — the same bits in every workgroup of the group — and go on to acc += yhat_i a_i.  The
+// exchange is PIPELINED one tile deep: tile p's partials are posted in step p and consumed in step p + 1, when every
+// partner has long posted them, so a workgroup never waits for the slowest of its group inside a step (with the
+// consumption in the same step the pass took 443 us against 374 us with the exchange compiled out: the workgroups of a
+// group ran in lockstep and every step cost the slowest one's load time plus the mailbox round trip).  Ring slot
+// (p + 3) mod 4 is refilled as soon as tile p - 1 has been accumulated: three tiles are in flight behind the one being
+// multiplied.  Four mailbox slots per group: a workgroup is never more than a step ahead of the slowest of its group
+// (step p + 1 needs everybody's partials of tile p).
+//
+// What keeps the loads flowing (each of these cost 10-25 % of the pass when it was missing):
+//  * the polls are SCALAR loads (s_load ... glc: the scalar cache bypassed, served by L2, counted on lgkmcnt).  A wave's
+//    vector-memory operations return in order, so a vector poll issued behind a prefetch does not come back before that
+//    whole tile has landed (tools/probes/spoll.hip: a scalar poll sees another workgroup's agent-scope store, same XCD
+//    or not, ~0.55 us per hop); a slice that stays unseen for long is also tried with vector loads, which are coherent
+//    whatever the placement of the group;
+//  * the rows' b, mu, mu*y and bounds come from LDS, filled once (read per tile they would queue behind the prefetch);
+//  * every tile load is unconditional — a row beyond the group's last one re-reads that last row and is never used, a
+//    lane beyond the last column reads column 0 against x = 0: with a branch around a load the compiler cannot count
+//    the loads in flight and waits for ALL of them (vmcnt(0)) before the first product;
+//  * one workgroup per CU: two (half the ring each) or narrower slices (16 or 32 partners) were 20-60 % slower.
+// With blockIdx round-robin over the XCDs the G workgroups of a group are placed on ONE XCD.
+// Output: c(x) (by slice 0), the partials of A'yhat per row group in k_gemv_t's layout part[group][col] — folded in
+// group order by k_gemv_t_finish as before — and the penalty partial sum(t^2 / mu) per group.
+// Every poll is bounded: a group whose workgroups are not all resident (another tenant holds CUs) reports a timeout
+// to the host instead of hanging; the host then goes back to the two-kernel form for good.
+// Both products are VALU fma: the matrix cores would need the yhat-weighted rows as a 16-row tile to fill their
+// accumulators (k_gemv_t_mfma feeds them 4 rows and wastes 15/16 of the result tile) — 16x the accumulator registers
+// this kernel spends on the tiles in flight; at 2 flop per 4 bytes the pass is HBM-bound either way.
+// ---------------------------------------------------------------------------
+constexpr int FBLOCK = 512;              // 8 waves, one workgroup per CU
+constexpr int FWAVES = FBLOCK / 64;
+constexpr int FT = 2;                    // rows per tile
+constexpr int FNB = 4;                   // tiles in the register ring
+constexpr int FG_MAX = 16;               // column slices (workgroups) per row group: at most two per polling wave
+constexpr int FMS = 4;                   // mailbox slots per group (ring over the tile sequence number)
+constexpr int FRC = 1024;                // rows per group, at most (their parameters sit in LDS)
+constexpr unsigned FSPIN_LIMIT = 8000000u;
+static_assert(FG_MAX <= 2 * FWAVES && FT == 2, "wave w polls slices w and w + 8; a slice's tagged pairs are one 32-byte scalar load");
+template <class T> struct DenseFusedArgs {
+    const T* A;
+    const T* x;
+    const T* b;
+    T* cx;                               // c(x) = A x - b
+    T* cx2;                              // ... a second copy (the affine images keep c at the current points), or null
+    T* part;                             // A'yhat partials: part[group * pstride + col]
+    int64_t pstride;
+    int64_t ny, n;
+    int G, ngroups;
+    int64_t rows_per_group;              // a multiple of FT
+    unsigned long long seq0;             // sequence number of this launch's first tile exchange
+    unsigned long long* mail;            // [ngroups][FMS][FG_MAX][FT][2] tagged words
+    int* timeout;
+    unsigned spin;
+    double* parts;
+    int slot_pen;
+    int sabotage;                        // (test) 1: slice 0 posts under a wrong tag: its partners' polls must give up, not hang
+};
+__device__ __forceinline__ void dev_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long dev_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+typedef unsigned bz_u8v __attribute__((ext_vector_type(8)));
+
+// The ring's loads are inline asm and so are the waits on them.  Left to the compiler, the wait in front of a tile's products
+// came out as vmcnt(0) — the three prefetched tiles drained at every turn of the ring: its bookkeeping merges the paths of the
+// poll loops and of the loop's back edge pessimistically.  An asm load is invisible to that bookkeeping; the wait statement
+// takes the tile's registers as in/out operands, so no product can be scheduled above it, and between a load and its wait
+// nothing reads those registers (checked in the generated code: tools/check_dense_ring.py).
+template <class T, int KP, int BI>
+__device__ __forceinline__ void dense_load_tile(typename PackVec<T>::type (&ring)[FNB][FT][KP], const unsigned (&off)[KP], const T* A,
+                                                const int64_t n, const int64_t r0, const int64_t r1, const int q) {
+    // tile q -> ring slot BI; a row beyond the group's last one re-reads that last row (never used)
+#pragma unroll
+    for (int r = 0; r < FT; ++r) {
+        const int64_t rr = r0 + (int64_t)q * FT + r;
+        const int64_t row = rr < r1 ? rr : r1 - 1;
+        const T* rp = A + row * n;
+#pragma unroll
+        for (int k = 0; k < KP; ++k)                                     // (streamed once: non-temporal)
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(ring[BI][r][k]) : "v"(off[k]), "s"(rp) : "memory");
+    }
+}
+// wait until at most two tiles' worth of this wave's vector-memory operations are outstanding: the two younger tiles stay in
+// flight, the tile in slot BI has landed (operations return in order; the two mailbox stores a step of wave 0 adds are older
+// than the tile behind them, so the same count holds there)
+template <class T, int KP, int BI>
+__device__ __forceinline__ void dense_wait_tile(typename PackVec<T>::type (&ring)[FNB][FT][KP]) {
+    constexpr int CNT = 2 * FT * KP;
+    static_assert(FT == 2 && CNT < 64, "");
+    if constexpr (KP == 4)
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ring[BI][0][0]), "+v"(ring[BI][0][1]), "+v"(ring[BI][0][2]), "+v"(ring[BI][0][3]),
+                     "+v"(ring[BI][1][0]), "+v"(ring[BI][1][1]), "+v"(ring[BI][1][2]), "+v"(ring[BI][1][3]) : "n"(CNT) : "memory");
+    else if constexpr (KP == 2)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ring[BI][0][0]), "+v"(ring[BI][0][1]), "+v"(ring[BI][1][0]), "+v"(ring[BI][1][1])
+                     : "n"(CNT) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ring[BI][0][0]), "+v"(ring[BI][1][0]) : "n"(CNT) : "memory");
+}
+
+template <class T, int KP>
+__global__ void __launch_bounds__(FBLOCK, 2 * (16 / (int)sizeof(T)) / KP)
+k_dense_fused(DenseFusedArgs<T> a, ElemParams<T> P) {
+    constexpr int N = PackN<T>::N;
+    __shared__ double sh_w[2][FWAVES][FT];      // (by step parity: a wave may write the next step's before a late one has read this step's)
+    __shared__ double sh_p[2][FG_MAX][FT];
+    __shared__ int sh_dead;
+    __shared__ T sh_rp[5][FRC];               // the group's rows: b, mu, mu*y, lower and upper bound
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // workgroup -> (row group, column slice): the slices of one group on one XCD
+    int lin = (int)blockIdx.x;
+    const int nblk = (int)gridDim.x;
+    if ((nblk & 7) == 0) lin = ((int)blockIdx.x & 7) * (nblk >> 3) + ((int)blockIdx.x >> 3);
+    const int group = lin / a.G, c = lin - group * a.G;
+    const int64_t npk = a.n / N;
+    unsigned off[KP];                    // byte offset of this lane's k-th pack inside a row (one 32-bit register per pack, rows
+    bool okk[KP];                        // addressed as uniform base + offset)
+    Pack<T> xs[KP], acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int64_t j = ((int64_t)c * KP + k) * FBLOCK + t;
+        okk[k] = j < npk;
+        off[k] = okk[k] ? (unsigned)(j * 16) : 0u;      // (a lane beyond the last column reads column 0 and multiplies it by x = 0)
+        xs[k] = okk[k] ? ldo<T, false>(a.x, off[k]) : splat(T(0));
+        acc[k] = splat(T(0));
+    }
+    if (t == 0) sh_dead = 0;
+    const int64_t r0 = (int64_t)group * a.rows_per_group;
+    const int64_t r1 = (r0 + a.rows_per_group < a.ny) ? r0 + a.rows_per_group : a.ny;
+    const int nph = r0 < r1 ? (int)((r1 - r0 + FT - 1) / FT) : 0;
+    double pen = 0.0;
+    unsigned long long* const mbox = a.mail + (size_t)group * (FMS * FG_MAX * FT * 2);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    using V = typename PackVec<T>::type;
+    V ring[FNB][FT][KP];
+    auto load_tile = [&](auto BI, const int q) { dense_load_tile<T, KP, decltype(BI)::value>(ring, off, a.A, a.n, r0, r1, q); };
+    // one slice's FT tagged pairs of tile sequence `seq` -> sh_p[par][sl][.]
+    auto poll_slice = [&](const int par, const int sl, const unsigned long long seq) {
+        const unsigned tag32 = ll_tag(seq);
+        const unsigned long long tag = (unsigned long long)tag32 << 32;
+        const unsigned long long* src = mbox + ((size_t)(seq % FMS) * FG_MAX + sl) * (FT * 2);
+        unsigned spins = 0;
+        for (;;) {
+            bz_u8v v;
+            asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(src) : "memory");
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < FT; ++r) ok = ok && v[4 * r + 1] == tag32 && v[4 * r + 3] == tag32;
+            if (ok) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < FT; ++r)
+                        sh_p[par][sl][r] = __longlong_as_double((long long)((unsigned long long)v[4 * r] | ((unsigned long long)v[4 * r + 2] << 32)));
+                }
+                return;
+            }
+            ++spins;
+            if ((spins & 4095u) == 0u) {                              // (rare: vector loads, coherent wherever the slices run)
+                unsigned long long w0 = 0, w1 = 0;
+                if (lane < FT) { w0 = dev_load(src + 2 * lane); w1 = dev_load(src + 2 * lane + 1); }
+                const bool mine = lane >= FT || ((w0 >> 32 << 32) == tag && (w1 >> 32 << 32) == tag);
+                if (__all(mine)) {
+                    if (lane < FT) sh_p[par][sl][lane] = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
+                    return;
+                }
+            }
+            if (spins > a.spin) {
+                if (lane == 0) { sh_dead = 1; *a.timeout = 8; }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    // Step p: the partial products of tile p are formed and posted; tile p - 1 — whose partials everybody posted a step ago —
+    // gets its yhat and is accumulated, and its ring slot takes tile p + 3.  BI = p mod 4.  Every step runs the same
+    // instruction stream with the same loads (steps beyond the last tile work on re-reads of the last row and skip the
+    // accumulation): the number of loads in flight at every wait is then known to the compiler, which otherwise waits for
+    // ALL of them — the three prefetched tiles included — at the first use.
+    auto step = [&](auto BI, const int p) -> bool {
+        constexpr int bi = decltype(BI)::value, bprev = (bi + FNB - 1) % FNB;
+        const int par = p & 1;
+        dense_wait_tile<T, KP, bi>(ring);
+#pragma unroll
+        for (int r = 0; r < FT; ++r) {
+            T s0 = T(0), s1 = T(0);
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+#pragma unroll
+                for (int e = 0; e < N; e += 2) {
+                    s0 = fma_t(ring[bi][r][k][e], xs[k].v[e], s0);
+                    s1 = fma_t(ring[bi][r][k][e + 1], xs[k].v[e + 1], s1);
+                }
+            const double v = wave_sum((double)s0 + (double)s1);
+            if (lane == 0) sh_w[par][wave][r] = v;
+        }
+        if (p > 0) {
+            if (a.sabotage == 2) {                                    // (timing experiment: no exchange, wrong values)
+                if (t < FT) for (int g = 0; g < a.G; ++g) sh_p[par][g][t] = 1.0;
+            } else {
+                const unsigned long long seq = a.seq0 + (unsigned long long)(p - 1);
+                if (wave_u < a.G) poll_slice(par, wave_u, seq);
+                if (wave_u + FWAVES < a.G) poll_slice(par, wave_u + FWAVES, seq);
+            }
+        }
+        __syncthreads();
+        if (sh_dead) return false;
+        if (t < FT) {
+            const unsigned long long seq = a.seq0 + (unsigned long long)p;
+            const unsigned long long tag = (unsigned long long)ll_tag(seq) << 32;
+            const double s = ((sh_w[par][0][t] + sh_w[par][1][t]) + (sh_w[par][2][t] + sh_w[par][3][t])) +
+                             ((sh_w[par][4][t] + sh_w[par][5][t]) + (sh_w[par][6][t] + sh_w[par][7][t]));
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+            unsigned long long* dst = mbox + (((size_t)(seq % FMS) * FG_MAX + c) * FT + t) * 2;
+            const unsigned long long ptag = (a.sabotage == 1 && c == 0) ? tag ^ (1ull << 62) : tag;
+            dev_store(dst + 0, ptag | (bits & 0xFFFFFFFFull));
+            dev_store(dst + 1, ptag | (bits >> 32));
+        }
+        const int64_t prow0 = r0 + (int64_t)(p - 1) * FT;            // first row of tile p - 1
+#pragma unroll
+        for (int r = 0; r < FT; ++r) {
+            const int64_t row = prow0 + r;
+            if (row < r0 || row >= r1) break;                        // (uniform over the workgroup)
+            const int rc = (int)(row - r0);
+            double dot = 0.0;
+            for (int g = 0; g < a.G; ++g) dot += sh_p[par][g][r];     // slice order: the same bits in every slice's workgroup
+            // eval!(cx, c, x) ; yupd = cx + muy ; proj!(s, D, yupd) ; yupd -= s ; sum(yupd^2 / mu) ; yupd /= mu   (auglagfun.jl:74-79)
+            const T dt = (T)dot;
+            const T cxv = a.b ? dt - sh_rp[0][rc] : dt;
+            const T mu = sh_rp[1][rc], muy = sh_rp[2][rc], lo = sh_rp[3][rc], hi = sh_rp[4][rc];
+            T tt = cxv + muy;
+            const T sv = proj_D(P.D_kind, tt, lo, hi);
+            tt = tt - sv;
+            const T pterm = (tt * tt) / mu;
+            const T yh = tt / mu;
+            if (c == 0 && t == 0) {
+                a.cx[row] = cxv;
+                if (a.cx2) a.cx2[row] = cxv;
+                pen += (double)pterm;
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+#pragma unroll
+                for (int e = 0; e < N; ++e) acc[k].v[e] = fma_t(yh, ring[bprev][r][k][e], acc[k].v[e]);
+        }
+        load_tile(std::integral_constant<int, bprev>{}, p + FNB - 1);
+        return true;
+    };
+
+    if (nph > 0) {
+        // the group's b, mu, mu*y and bounds into LDS, once (read per tile as vector loads they would queue behind the
+        // prefetched tiles — a wave's loads return in order)
+        for (int i = t; i < (int)(r1 - r0); i += FBLOCK) {
+            const int64_t row = r0 + i;
+            sh_rp[0][i] = a.b ? a.b[row] : T(0);
+            sh_rp[1][i] = P.uni >= 1 ? P.mu_uniform : P.mu[row];
+            sh_rp[2][i] = P.uni >= 2 ? T(0) : P.muy[row];
+            sh_rp[3][i] = P.D_lo_vec ? P.D_lo_vec[row] : P.D_lo;
+            sh_rp[4][i] = P.D_hi_vec ? P.D_hi_vec[row] : P.D_hi;
+        }
+        // (x is needed in registers BEFORE the ring starts: a wait the compiler places at its first use inside the loop would be
+        // a vmcnt(0) there — it does not see the ring's loads — and drain the ring at every turn)
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+#pragma unroll
+            for (int e = 0; e < N; ++e) asm volatile("" : "+v"(xs[k].v[e]));
+        load_tile(std::integral_constant<int, 0>{}, 0);
+        load_tile(std::integral_constant<int, 1>{}, 1);
+        load_tile(std::integral_constant<int, 2>{}, 2);
+        const int nsteps = (nph + 1 + FNB - 1) / FNB * FNB;          // steps 0 .. nph, padded to whole turns of the ring
+        for (int p = 0; p < nsteps; p += FNB) {                      // (a poll that gave up ends the workgroup: no path skips a step)
+            if (!step(std::integral_constant<int, 0>{}, p)) return;
+            if (!step(std::integral_constant<int, 1>{}, p + 1)) return;
+            if (!step(std::integral_constant<int, 2>{}, p + 2)) return;
+            if (!step(std::integral_constant<int, 3>{}, p + 3)) return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+        if (okk[k]) sto<T, false>(a.part + (int64_t)group * a.pstride, off[k], acc[k]);
+    if (c == 0 && t == 0) a.parts[(size_t)a.slot_pen * PSTRIDE + group] = pen;
+}
+
 // Halo exchange of the row-block-sharded stencil: this rank's first grid row goes to the previous rank's
 // "south" halo and its last row to the next rank's "north" halo, straight into the neighbours' HBM through
 // the IPC mapping (plain 16-byte stores), then a system-scope release and a sequence-number flag; then wait

@@ -100,6 +100,9 @@ struct GateTimeout : Error {
     explicit GateTimeout(int code) : Error(BZ_ERR_COMM, code == 6 ? "a pre-launched pass timed out at its gate (the host never released it)"
                                                                    : "a pre-launched pass: workgroups timed out waiting for workgroup 0 to open the gate") {}
 };
+struct DenseFusedTimeout : Error {
+    DenseFusedTimeout() : Error(BZ_ERR_HIP, "one-pass dense kernel: a row group's workgroups timed out waiting for each other (not all resident?)") {}
+};
 struct PersistTimeout : Error {
     PersistTimeout() : Error(BZ_ERR_HIP, "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)") {}
 };
@@ -238,8 +241,9 @@ template <class T> class Solver final : public SolverBase {
             upload(cb_, d.c_b, ny);
             CX_.alloc(ny); YU_.alloc(ny);
             plan_chunks(ny, rows_per_chunk, nrowchunks);
-            GT_.alloc((size_t)nrowchunks * npad);
             x_replicated = ctx->nranks > 1;
+            dense_fused_plan();
+            GT_.alloc((size_t)std::max(nrowchunks, df_groups_) * npad);
             if (x_replicated) JL_.alloc(npad);
             affine_ok_ = !x_replicated && !slack && (d.D_kind == BZ_D_ZERO || d.D_kind == BZ_D_FREE) &&
                          (d.f_kind == BZ_F_ZERO || d.f_kind == BZ_F_DIAG_QUADRATIC);
@@ -1282,6 +1286,85 @@ template <class T> class Solver final : public SolverBase {
     }
     // ---- row-sharded dense constraint: x replicated, A' yhat summed over the ranks --------------------
     // region layout: slots[parity][rank][npad] of T, then flags[parity][rank]
+    // ---- dense constraint in ONE pass over A (k_dense_fused) ------------------------------------------
+    bool dense_fused_broken_ = false;
+    int64_t n_dense_fallbacks_ = 0, n_dense_onepass_ = 0;
+    int df_kp_ = 0, df_G_ = 0, df_groups_ = 0;
+    int64_t df_rpg_ = 0;
+    unsigned long long df_seq_ = 1;
+    DBuf<unsigned long long> df_mail_;
+    // the plan for an ny x n matrix on this device, or df_kp_ = 0 when the kernel does not apply
+    template <int KP_> static int dense_occupancy() {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_dense_fused<T, KP_>, FBLOCK, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            occ = 0;
+        }
+        return occ;
+    }
+    void dense_fused_plan() {
+        df_kp_ = 0;
+        df_env_ = std::getenv("BZ_DENSE_FUSED") ? std::atoi(std::getenv("BZ_DENSE_FUSED")) : 1;
+        df_sabotage_ = std::getenv("BZ_TEST_DENSE_TIMEOUT") ? std::atoi(std::getenv("BZ_TEST_DENSE_TIMEOUT")) : 0;
+        df_spin_ = std::getenv("BZ_DENSE_SPIN") ? (unsigned)std::atoll(std::getenv("BZ_DENSE_SPIN")) : 0u;
+        constexpr int N = PackN<T>::N;
+        if (desc.c_kind != BZ_C_DENSE_AFFINE || x_replicated || slack || (n % N) != 0) return;
+        if (desc.D_kind >= BZ_D_VC_PAIRS) return;
+        const int64_t npk = n / N;
+        // KP packs per row and lane: kp_full fills a CU's registers with ONE workgroup's ring of tiles — the fewest slices per
+        // row group, so the fewest partners per exchange (narrower slices: 16 or 32 partners, and several workgroups per CU,
+        // measured 20-60 % slower on cfg 4); the narrower forms serve matrices with few columns
+        const int kp_full = std::is_same<T, float>::value ? 4 : 2;
+        int kp = kp_full;
+        if (const char* e = std::getenv("BZ_DENSE_KP")) kp = std::max(1, std::min(kp_full, std::atoi(e)));
+        while (kp > 1 && kp != 2 && kp != 4) --kp;
+        while (kp > 1 && (int64_t)FBLOCK * (kp / 2) >= npk) kp /= 2;       // (a matrix narrower than one slice: more row groups instead)
+        while (kp < kp_full && (npk + (int64_t)FBLOCK * kp - 1) / ((int64_t)FBLOCK * kp) > FG_MAX) kp *= 2;
+        const int64_t G = (npk + (int64_t)FBLOCK * kp - 1) / ((int64_t)FBLOCK * kp);
+        // co-resident workgroups: what the runtime says fits a CU, at most what the launch bounds ask for (the groups' workgroups
+        // wait for each other: a grid beyond the resident set would only ever time out)
+        int occ = 0;
+        if (kp == 1) occ = dense_occupancy<1>();
+        else if (kp == 2) occ = dense_occupancy<2>();
+        else if constexpr (std::is_same<T, float>::value) occ = dense_occupancy<4>();
+        const int64_t slots = (int64_t)num_cus * std::min(occ, kp_full / kp);
+        if (G > FG_MAX || G > slots) return;
+        int64_t groups = std::max<int64_t>(1, std::min<int64_t>(slots / G, (ny + FT - 1) / FT));
+        int64_t rpg = (ny + groups - 1) / groups;
+        rpg = (rpg + FT - 1) / FT * FT;
+        groups = (ny + rpg - 1) / rpg;
+        if (rpg > FRC) return;                                          // (a group's row parameters must fit the kernel's LDS cache)
+        df_kp_ = kp; df_G_ = (int)G; df_groups_ = (int)groups; df_rpg_ = rpg;
+        df_mail_.alloc((size_t)groups * FMS * FG_MAX * FT * 2);
+    }
+    bool dense_fused_on() const { return df_env_ && df_kp_ > 0 && !dense_fused_broken_; }
+    int df_env_ = 1, df_sabotage_ = 0;       // BZ_DENSE_FUSED / BZ_TEST_DENSE_TIMEOUT, read when the problem is created
+    unsigned df_spin_ = 0;                   // BZ_DENSE_SPIN
+    // gradient!'s dense part in one pass over A: c(point) -> CX_ (and cx_keep_), the row-group partials of A'yhat -> GT_,
+    // the penalty partials -> slot_pen
+    void dense_fused_launch(const T* x, int slot_pen) {
+        DenseFusedArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        a.A = A_.p; a.x = x; a.b = cb_.p; a.cx = CX_.p; a.cx2 = cx_keep_; a.part = GT_.p; a.pstride = npad;
+        a.ny = ny; a.n = n; a.G = df_G_; a.ngroups = df_groups_; a.rows_per_group = df_rpg_;
+        a.seq0 = df_seq_; a.mail = df_mail_.p; a.timeout = ptimeout_dev_;
+        a.spin = df_spin_ ? df_spin_ : FSPIN_LIMIT;
+        a.parts = parts_.p; a.slot_pen = slot_pen;
+        df_seq_ += (unsigned long long)(df_rpg_ / FT) + 2ull * FNB;      // (every step posts, the padding steps of the last ring turn too)
+        // (test) slice 0 of every group posts under tags nobody waits for: the polls give up
+        if (df_sabotage_ > 0 && ++dense_sabotage_count_ == df_sabotage_) a.sabotage = 1;
+        if (df_sabotage_ == -2) a.sabotage = 2;      // (timing experiment: no exchange)
+        // the matrix once; x, b and the penalty vectors over the rows; c(x) out; the row-group partials
+        mv((double)ny, n); mv(1, n); mv(2 + pstreams(false, true, false) + (cx_keep_ ? 1 : 0), ny); mv(df_groups_, npad);
+        const int g = df_groups_ * df_G_;
+        if (df_kp_ == 1) { nm("k_dense_fused<KP=1>"); launch_b(C_GEMV, k_dense_fused<T, 1>, g, FBLOCK, a, P); }
+        else if (df_kp_ == 2) { nm("k_dense_fused<KP=2>"); launch_b(C_GEMV, k_dense_fused<T, 2>, g, FBLOCK, a, P); }
+        else if constexpr (std::is_same<T, float>::value) { nm("k_dense_fused<KP=4>"); launch_b(C_GEMV, k_dense_fused<T, 4>, g, FBLOCK, a, P); }
+        else throw Error(BZ_ERR_STATE, "k_dense_fused: no instantiation");
+        slot_n[slot_pen] = df_groups_;
+        ++n_dense_onepass_;
+    }
+    int dense_sabotage_count_ = 0;
     bool x_replicated = false;
     DBuf<T> JL_;                     // this rank's partial of A' yhat
     void* ar_local_ = nullptr;
@@ -1511,6 +1594,10 @@ template <class T> class Solver final : public SolverBase {
             *ptimeout_ = 0;
             if (code == 1 && ctx->nranks == 1) throw PersistTimeout();
             if (code == 6 || code == 7) throw GateTimeout(code);
+            if (code == 8) {      // (whoever can redo its work does; every later evaluation takes the two-kernel form)
+                dense_fused_broken_ = true; ++n_dense_fallbacks_;
+                throw DenseFusedTimeout();
+            }
             throw Error(code == 1 ? BZ_ERR_HIP : BZ_ERR_COMM,
                         code == 1 ? "persistent two-loop kernel: grid barrier timed out (blocks not co-resident?)"
                         : code == 2 ? "p2p scalar exchange timed out waiting for a peer rank"
@@ -1619,6 +1706,15 @@ template <class T> class Solver final : public SolverBase {
     }
     void algrad(const T* x, T* grad, int slot0) {
         if (generic_) { algrad_generic(x, grad, slot0); return; }
+        if (desc.c_kind == BZ_C_DENSE_AFFINE && dense_fused_on()) {
+            // one pass over A: c(x), yhat and the row-group partials of A'yhat (k_dense_fused), then the fold + f terms
+            slot_n[slot0] = grid;
+            dense_fused_launch(x, slot0 + 1);
+            mv(df_groups_ + 2 + pstreams(true, false, false));
+            launch(C_MISC, k_gemv_t_finish<T>, grid, (const T*)GT_.p, df_groups_, npad, x, P, grad, n, parts_.p, slot0);
+            gather(slot0, 2, 0u, 2u);
+            return;
+        }
         if (desc.c_kind == BZ_C_DENSE_AFFINE) {
             eval_c(x);                                                        // cx = A x - b
             if (cx_keep_) BZ_HIP(hipMemcpyAsync(cx_keep_, CX_.p, ny * sizeof(T), hipMemcpyDeviceToDevice, cur_));
@@ -2037,6 +2133,18 @@ template <class T> class Solver final : public SolverBase {
 
     // ------------------------------------------------ Base.iterate(iter)  (k = 1)
     void begin_dev(const bz_panoc_opts& o, const T* x0_dev) {
+        try {
+            begin_impl(o, x0_dev);
+        } catch (const DenseFusedTimeout&) {
+            // (the start of a solve writes nothing it does not write again: once more, in the two-kernel form)
+            if (ctx->nranks > 1) throw;
+            BZ_HIP(hipStreamSynchronize(cur_));
+            *ptimeout_ = 0;
+            std::fprintf(stderr, "Warning: the one-pass dense kernel timed out (is the GPU shared?); using the two-kernel form\n");
+            begin_impl(o, X_[0].p);
+        }
+    }
+    void begin_impl(const bz_panoc_opts& o, const T* x0_dev) {
         opt = o;
         if (o.lbfgs_memory < 0 || o.lbfgs_memory > MAX_MEM)
             throw Error(BZ_ERR_ARG, "lbfgs_memory must be in 0..16 (0 = NoAcceleration)");
@@ -2084,7 +2192,7 @@ template <class T> class Solver final : public SolverBase {
         static const int aff_env = std::getenv("BZ_AFFINE") ? std::atoi(std::getenv("BZ_AFFINE")) : -1;
         if (aff_env >= 0) aff_refresh_ = aff_env;
         aff_track_ = affine_ok_ && aff_refresh_ > 0 && o.lbfgs_compact != 0 && M >= 1 && M <= CM && dir_kind_ == BZ_DIR_LBFGS;
-        aff_count_ = 0; n_affine_ = 0; n_gated_ = 0; n_gate_aborts_ = 0;
+        aff_count_ = 0; n_affine_ = 0; n_gated_ = 0; n_gate_aborts_ = 0; n_dense_onepass_ = 0;
         compact_ok = M >= 1 && (o.lbfgs_compact == 1 || dir_kind_ == BZ_DIR_ANDERSON ||
                                 (o.lbfgs_compact == 2 && (fused_ok || stencil_fast_ || aff_track_) && M <= CM));
         {
@@ -2305,6 +2413,18 @@ template <class T> class Solver final : public SolverBase {
                 restore();
                 gate_broken_ = true; gate_env_ = 0; ++n_gate_fallbacks_;
                 std::fprintf(stderr, "Warning: a pre-launched pass timed out at its gate (is the GPU shared?); gated pre-launch is off for this problem\n");
+                step_impl();
+            } catch (const DenseFusedTimeout&) {
+                // the one-pass dense kernel's workgroups wait for each other (k_dense_fused): with CUs held by somebody else a
+                // row group can be partly resident — the two-kernel form from now on, and the iteration again
+                if (ctx->nranks > 1) throw;
+                gate_abort();
+                BZ_HIP(hipStreamSynchronize(cur_));
+                cur_ = ctx->stream;
+                *ptimeout_ = 0;
+                restore();
+                aff_count_ = aff_refresh_;      // (the images of this iteration's points were being formed: evaluate afresh)
+                std::fprintf(stderr, "Warning: the one-pass dense kernel timed out (is the GPU shared?); using the two-kernel form\n");
                 step_impl();
             } catch (const PersistTimeout&) {
                 if (!persist_ok) throw;
@@ -2876,6 +2996,8 @@ template <class T> class Solver final : public SolverBase {
         st->n_gated_launches = n_gated_;
         st->n_gate_aborts = n_gate_aborts_;
         st->n_gate_fallbacks = n_gate_fallbacks_;
+        st->n_dense_onepass = n_dense_onepass_;
+        st->n_dense_fallbacks = n_dense_fallbacks_;
     }
 };
 

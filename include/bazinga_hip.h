@@ -306,6 +306,10 @@ typedef struct {
                                  first workgroup was not resident in time because another tenant holds the GPU's CUs —
                                  and the iteration was redone without the gate, which then stays off for this problem
                                  (0 or 1; one rank only: with several ranks it is BZ_ERR_COMM)                        */
+    int64_t n_dense_onepass;  /* (r03) AL gradients with c = DenseAffine evaluated in ONE pass over A (k_dense_fused: c(x), yhat and
+                                 A'yhat from one read of every row, demo/basispursuit.jl:38-49) instead of two products         */
+    int64_t n_dense_fallbacks;/* times that kernel's row groups timed out waiting for each other (workgroups not all resident:
+                                 the GPU has another tenant) and the solve went on with the two-kernel form (0 or 1)           */
 } bz_panoc_stats;
 
 /* Multipliers/penalties of the current subproblem:  AugLagUpdate!(alFun, mu, y)

@@ -49,6 +49,7 @@ Base.@kwdef mutable struct PanocStats
     n_backtracks::Int64 = 0; n_gamma_halvings::Int64 = 0; n_fused_iters::Int64 = 0
     n_lbfgs_skips::Int64 = 0; elapsed_s::Float64 = 0; status::Int32 = 0; persist_fallbacks::Int32 = 0
     n_affine_images::Int64 = 0; n_gated_launches::Int64 = 0; n_gate_aborts::Int64 = 0; n_gate_fallbacks::Int64 = 0
+    n_dense_onepass::Int64 = 0; n_dense_fallbacks::Int64 = 0
 end
 
 Base.@kwdef mutable struct AlpsOpts

@@ -50,11 +50,16 @@ def test_dense_iterates_follow_oracle_with_and_without_affine_images(bz, ref, sh
     prob.close()
 
 
-def test_affine_images_halve_the_passes_over_A(bz, ref):
-    """traffic accounting: with images the gemv categories see 2 launches per iteration instead of 4"""
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_affine_images_halve_the_passes_over_A(bz, ref, fused, monkeypatch):
+    """traffic accounting (bytes the launches are designed to move, in passes over A): an AL gradient is ONE pass with the
+    one-pass kernel and two as k_gemv_n + k_gemv_t; an iteration evaluates two gradients, one of them (at the trial point)
+    replaced by images between refreshes"""
     ny, n = 512, 4096
+    monkeypatch.setenv("BZ_DENSE_FUSED", fused)
     d, dev, orc = make_cfg4(bz, ref, ny, n, np.float32, density=0.05)
     mu, y, x0 = np.full(ny, 0.1, np.float32), np.zeros(ny, np.float32), np.zeros(n, np.float32)
+    per_grad = 1 if fused == "1" else 2
     counts = {}
     for refresh in (0, 8):
         prob = bz.Problem(*dev, n, ny, np.float32)
@@ -65,10 +70,14 @@ def test_affine_images_halve_the_passes_over_A(bz, ref):
         prob.panoc_steps(16)
         p = prob.profile2()
         st = prob.panoc_stats()
-        counts[refresh] = (p["gemv"]["launches"] + p["k_gemv_t_mfma"]["launches"], st.n_backtracks, st.n_gamma_halvings)
+        passes = (p["gemv"]["bytes"] + p["k_gemv_t_mfma"]["bytes"]) / (4.0 * ny * n)
+        counts[refresh] = (passes, st.n_backtracks, st.n_gamma_halvings, st.n_dense_onepass, p["gemv"]["form"])
         prob.close()
-    assert counts[0][0] >= 4 * 16
-    assert counts[8][0] <= 2 * 16 + 2 * 2 + 4 * (counts[8][1] + counts[8][2]) + 2      # two refreshes in 16 iterations
+    assert counts[0][0] >= 2 * per_grad * 16
+    # two refreshes in 16 iterations; a backtrack or a halving costs up to four more gradients (a failing step-size test on
+    # images is re-run on evaluations, then the trial is repeated)
+    assert counts[8][0] <= per_grad * (16 + 2 + 4 * (counts[8][1] + counts[8][2]) + 3) * 1.01
+    assert (counts[0][3] > 0) == (fused == "1") and counts[0][4].startswith("k_dense_fused" if fused == "1" else "k_gemv_n")
 
 
 def test_affine_images_with_diag_quadratic_f_and_free_set(bz, ref):
@@ -94,8 +103,9 @@ def test_affine_images_with_diag_quadratic_f_and_free_set(bz, ref):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("refresh,states", [(16, 22), (8, 8), (0, 8)])
-def test_dense_full_size_iterates_fp32(bz, ref, refresh, states):
+@pytest.mark.parametrize("refresh,states,onepass", [(16, 22, True), (8, 8, True), (0, 8, True), (16, 8, False)],
+                         ids=["refresh16-22states", "refresh8", "no-images", "two-kernel-form"])
+def test_dense_full_size_iterates_fp32(bz, ref, refresh, states, onepass, monkeypatch):
     """BASELINE config 4 at full size (A 8192 x 65536 fp32 = 2 GiB) against the numpy oracle in fp32, the MFMA
     transposed product in the loop: at the SHIPPED default affine_refresh = 16 — what `bench.py --workload cfg4` times —
     for 22 states, so that a pass-over-A refresh of the images is crossed (iteration 16) and five more iterations run on
@@ -108,17 +118,25 @@ def test_dense_full_size_iterates_fp32(bz, ref, refresh, states):
     ny, n = 8192, 65536
     d, dev, orc = full_size_cfg4(bz, ref)
     mu, y, x0 = np.full(ny, 0.1, np.float32), np.zeros(ny, np.float32), np.zeros(n, np.float32)
+    # (the library default is the one-pass kernel: every row of A read once per gradient; BZ_DENSE_FUSED=0 keeps k_gemv_n and
+    # the MFMA transposed product, which stay the form of the row-sharded and dense-f paths)
+    monkeypatch.setenv("BZ_DENSE_FUSED", "1" if onepass else "0")
     prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, x0, states, minimum_gamma=float(np.finfo(np.float32).eps),
                                 dtype=np.float32, ny=ny, affine_refresh=refresh)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"cfg4_full_rows_refresh{refresh}.log"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", f"cfg4_full_rows_refresh{refresh}{'' if onepass else '_two_kernel'}.log"), "w") as fh:
         for r in rows:
             fh.write("k=%d ex=%.3e ez=%.3e gamma_dev=%.9g gamma_ref=%.9g stop_dev=%.4e stop_ref=%.4e fused=%d sens=%.3e\n" % tuple(r))
     for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
-        assert sens <= 1e-4, (k, sens)
-        assert abs(g_d - g_r) <= 1e-4 * g_r, (k, g_d, g_r)
-        assert ex <= max(2e-4, 100 * sens) and ez <= max(2e-4, 100 * sens), (k, ex, ez, sens)
+        # measured (r03, gpurun_out/cfg4_full_rows_refresh*.log): the oracle's own sensitivity stays below 1e-6 over the 22
+        # states and the device within 1.5e-6 of it — one fp32 product over n = 65536 terms rounds to ~1e-5; no envelope
+        # that scales with the oracle's noise is needed, so none is used
+        assert sens <= 1e-5, (k, sens)
+        assert abs(g_d - g_r) <= 1e-5 * g_r, (k, g_d, g_r)
+        assert ex <= 1e-5 and ez <= 1e-5, (k, ex, ez, sens)
     stats = prob.panoc_stats()
+    assert stats.n_dense_fallbacks == 0
+    assert (stats.n_dense_onepass >= states - 1) if onepass else (stats.n_dense_onepass == 0)      # (every gradient at z: one pass over A)
     if refresh:
         # every iteration but the refreshes (and wherever a step-size test failed on images) ran on images
         its = states - 1
@@ -129,6 +147,97 @@ def test_dense_full_size_iterates_fp32(bz, ref, refresh, states):
     prob.profile_enable(True)
     prob.panoc_steps(4)
     p = prob.profile2()
-    assert p["k_gemv_t_mfma"]["launches"] >= 4 and p["k_gemv_t_mfma"]["form"] == "k_gemv_t_mfma"
-    assert 8.0e12 >= p["k_gemv_t_mfma"]["timed_bytes"] / (p["k_gemv_t_mfma"]["timed_ms"] * 1e-3) >= 3.0e12
+    if onepass:
+        assert p["gemv"]["launches"] >= 4 and p["gemv"]["form"].startswith("k_dense_fused<KP=4") and p["k_gemv_t_mfma"]["launches"] == 0
+        assert 8.0e12 >= p["gemv"]["timed_bytes"] / (p["gemv"]["timed_ms"] * 1e-3) >= 3.0e12
+    else:
+        assert p["k_gemv_t_mfma"]["launches"] >= 4 and p["k_gemv_t_mfma"]["form"] == "k_gemv_t_mfma"
+        assert 8.0e12 >= p["k_gemv_t_mfma"]["timed_bytes"] / (p["k_gemv_t_mfma"]["timed_ms"] * 1e-3) >= 3.0e12
     prob.close()
+
+
+# ---- the dense constraint in ONE pass over A (k_dense_fused; demo/basispursuit.jl:38-49) --------------------
+ONEPASS_SHAPES = [(5, 12), (64, 512), (257, 1028), (1030, 4100), (300, 20000), (33, 3000), (2051, 16384)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", ONEPASS_SHAPES, ids=[f"{a}x{b}" for a, b in ONEPASS_SHAPES])
+@pytest.mark.parametrize("D", ["zero", "free", "box"])
+def test_dense_one_pass_gradient_matches_oracle_and_two_kernel_form(bz, ref, shape, dtype, D, monkeypatch):
+    """gradient!(dlx, al, x) (auglagfun.jl:73-86) with c(x) = A x - b: the one-pass kernel (every row of A read once; row
+    groups shared by G workgroups that exchange partial products) against the numpy oracle and against the two-kernel form
+    (k_gemv_n + k_gemv_t), over ragged shapes: rows not a multiple of the 4-row tile, a last column slice with a single
+    pack, one slice and many, more row groups than rows."""
+    ny, n = shape
+    rng = np.random.default_rng(ny * 7 + n)
+    A = (rng.standard_normal((ny, n)) / np.sqrt(ny)).astype(dtype)
+    b = rng.standard_normal(ny).astype(dtype)
+    x = (rng.standard_normal(n) * (rng.random(n) < 0.2)).astype(dtype)
+    mu = (10.0 ** rng.uniform(-2, 0, ny)).astype(dtype)
+    y = rng.standard_normal(ny).astype(dtype)
+    mk = {"zero": lambda m: m.ZeroSet(), "free": lambda m: m.FreeSet(),
+          "box": lambda m: m.ClosedSet(m.IndBox(dtype(-0.3), dtype(0.4)) if m is ref else m.IndBox(-0.3, 0.4))}[D]
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("BZ_DENSE_FUSED", fused)
+        prob = bz.Problem(bz.Zero(), bz.NormL1(1.0), bz.DenseAffine(A, b), mk(bz), n, ny, dtype)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(dtype).eps)).c_opts(), x)
+        onepass = prob.panoc_stats().n_dense_onepass
+        assert (onepass >= 2) == (fused == "1"), onepass
+        outs[fused] = prob.eval_al_gradient(x)
+        prob.close()
+    al = ref.AugLagFun(ref.Zero(), ref.DenseAffine(A, b), mk(ref), mu.copy(), y.copy(), x)
+    g_ref = np.empty(n, dtype)
+    L_ref = al.gradient(g_ref, x)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    scale = max(1.0, float(np.max(np.abs(g_ref))))
+    for fused in ("1", "0"):
+        g, vals = outs[fused]
+        assert np.max(np.abs(g - g_ref)) <= tol * scale, (fused, np.max(np.abs(g - g_ref)))
+        assert abs(vals[0] - L_ref) <= tol * max(1.0, abs(L_ref)), (fused, vals[0], L_ref)
+    assert np.max(np.abs(outs["1"][0] - outs["0"][0])) <= tol * scale
+
+
+def test_dense_one_pass_is_deterministic(bz, ref):
+    """the partial products meet in slice order and the row groups fold in group order whatever the arrival order: two
+    evaluations give the same bits"""
+    ny, n = 513, 8192
+    d, dev, orc = make_cfg4(bz, ref, ny, n, np.float32, density=0.05)
+    mu, y = np.full(ny, 0.1, np.float32), (0.1 * np.random.default_rng(2).standard_normal(ny)).astype(np.float32)
+    x = np.random.default_rng(3).standard_normal(n).astype(np.float32)
+    prob = bz.Problem(*dev, n, ny, np.float32)
+    prob.set_multipliers(mu, y)
+    g0, v0 = prob.eval_al_gradient(x)
+    for _ in range(5):
+        g1, v1 = prob.eval_al_gradient(x)
+        assert np.array_equal(g0, g1) and v0 == v1
+    prob.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("where", ["in-the-loop", "at-the-start"])
+def test_dense_one_pass_timeout_falls_back_to_two_kernels(bz, ref, monkeypatch, where):
+    """The G workgroups of a row group wait for each other's partial products: with CUs held by another tenant a group can be
+    partly resident.  Every poll is bounded; a group that gives up reports it, the host redoes the iteration (or the start of
+    the solve) with the two-kernel form and stays there.  (BZ_TEST_DENSE_TIMEOUT=k: in the k-th launch slice 0 posts under
+    tags nobody waits for; BZ_DENSE_SPIN shortens the poll bound.)"""
+    ny, n = 600, 8192          # G = 4 slices
+    d, dev, orc = make_cfg4(bz, ref, ny, n, np.float32, density=0.05)
+    mu, y, x0 = np.full(ny, 0.1, np.float32), np.zeros(ny, np.float32), np.zeros(n, np.float32)
+    monkeypatch.setenv("BZ_DENSE_SPIN", "20000")
+    monkeypatch.setenv("BZ_TEST_DENSE_TIMEOUT", "9" if where == "in-the-loop" else "2")
+    prob = bz.Problem(*dev, n, ny, np.float32)
+    prob.set_multipliers(mu, y)
+    z, st = prob.panoc_solve(bz.PANOCplus(tol=1e-4, maxit=400, minimum_gamma=1e-7).c_opts(), x0)
+    assert st.n_dense_fallbacks == 1 and st.status == 0
+    prob.close()
+    monkeypatch.setenv("BZ_TEST_DENSE_TIMEOUT", "0")
+    monkeypatch.setenv("BZ_DENSE_FUSED", "0")
+    prob = bz.Problem(*dev, n, ny, np.float32)
+    prob.set_multipliers(mu, y)
+    z2, st2 = prob.panoc_solve(bz.PANOCplus(tol=1e-4, maxit=400, minimum_gamma=1e-7).c_opts(), x0)
+    prob.close()
+    assert st2.n_dense_fallbacks == 0 and st2.n_dense_onepass == 0
+    assert abs(st.iters - st2.iters) <= max(3, 0.1 * st2.iters)
+    assert np.max(np.abs(z - z2)) <= 1e-3 * max(1.0, np.max(np.abs(z2)))

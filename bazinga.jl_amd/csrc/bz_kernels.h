@@ -3151,8 +3151,10 @@ k_fused_compact(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ x
 // lifted vector), so the scalars agree with it to rounding.  Slots: those of k_fused_compact.
 // ---------------------------------------------------------------------------
 template <class T> struct SlackOut { T gx, gs, fterm, pterm; };
+// (udiv: mu is uniform over the launch and rmu = RN(1 / mu): the quotients through two Markstein steps, div_u — the bits of
+// the hardware division in half the instructions)
 template <class T>
-__device__ __forceinline__ SlackOut<T> slack_elem(int f_kind, T x, T sv, T q, T b, T mu, T muy, T y) {
+__device__ __forceinline__ SlackOut<T> slack_elem(int f_kind, T x, T sv, T q, T b, T mu, T muy, T y, bool udiv = false, T rmu = T(0)) {
     SlackOut<T> o;
     T dfx = T(0);
     o.fterm = T(0);
@@ -3164,9 +3166,9 @@ __device__ __forceinline__ SlackOut<T> slack_elem(int f_kind, T x, T sv, T q, T 
     const T cx = x;
     T w = cx + muy;
     w = w - sv;
-    o.pterm = (w * w) / mu;
+    o.pterm = udiv ? div_u(w * w, mu, rmu) : (w * w) / mu;
     const T r = cx - sv;
-    const T yupd = y + r / mu;
+    const T yupd = y + (udiv ? div_u(r, mu, rmu) : r / mu);
     o.gx = dfx + yupd;
     o.gs = -yupd;
     return o;
@@ -3193,7 +3195,7 @@ k_fused_slack(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ xs,
         load_params<T, NT>(P, i0, cnt, L, true, true, true);
         Pack<T> dlo = P.D_lo_vec ? ldp<T, NT>(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
         Pack<T> dhi = P.D_hi_vec ? ldp<T, NT>(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
-        Pack<T> pyv = ldp<T, NT>(yv, i0, cnt);
+        Pack<T> pyv = P.uni >= 2 ? splat(T(0)) : ldp<T, NT>(yv, i0, cnt);
         // both halves of every lifted vector: h = 0 the x part, h = 1 the s part
         Pack<T> px[2], prp[2], ps[2][MM], py[2][MM], d[2];
 #pragma unroll
@@ -3282,6 +3284,236 @@ k_fused_slack(CompactVecs<T, MM> V, CompactCoef<MM> C, const T* __restrict__ xs,
     });
     if constexpr (NS == 32) block_reduce_store32(acc, 1u << 9, parts, slot0);
     else block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
+}
+
+// ---------------------------------------------------------------------------
+// The slack form with the history as ITERATES (r03; the headline kernel's XR = 2 idea on xs = [x; s]): the stored pairs are
+// differences of consecutive iterates and of their fixed-point residuals, and the residual of an iterate is a function of
+// that iterate alone — res = xs - [prox_{gamma g}; proj_D](xs - gamma grad F(xs)) with gamma, mu, mu*y, y fixed along
+// the run (src/utilities/auglagfunslack.jl:78-97,136-154).  So the pass reads the m + 1 last iterates (both halves), re-
+// evaluates their residuals in registers — the operations of k_fused_slack on the same operands, so the same bits — forms
+// the pairs by the very subtractions that produced the stored ones, and from there on IS k_fused_slack; it writes xs_d
+// only (z on request): 2 (m + 1) + 2 passes over n plus the parameter vectors instead of 2 (2m + 7): 1.5 GB instead of
+// 2.96 GB per iteration at n = 1e7, m = 5.  XH[0..m]: the iterates, oldest first, XH[m] the current one; gam0: the step
+// size the OLDEST iterate's residual was formed with (CompactCoef::gam0; every younger one: gamma).
+// ---------------------------------------------------------------------------
+template <class T, int MM> struct SlackIterates {
+    const T* XH[MM + 1];
+    int m;
+};
+template <class T>
+__device__ __forceinline__ void slack_resid(const ElemParams<T>& P, T x, T sv, const ElemLoads<T>& L, int e, T dlo, T dhi, T yv,
+                                            T gam, T& rx, T& rs, T& zx, T& zs, bool udiv = false, T rmu = T(0)) {
+    const SlackOut<T> o = slack_elem(P.f_kind, x, sv, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], yv, udiv, rmu);
+    T t = gam * o.gx;
+    const T yx = x - t;
+    T u = gam * o.gs;
+    const T ys = sv - u;
+    T gterm;
+    zx = prox_elem(P.g_kind, yx, gam * P.g_lambda, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+    zs = proj_D(P.D_kind, ys, dlo, dhi);
+    rx = x - zx;
+    rs = sv - zs;
+}
+// FULL: the memory holds MM pairs (the steady state): compile-time trip counts, so the 2 (MM + 1) iterate loads issue back
+// to back with no branch between them (with a branch around a load the compiler waits for every load at the first use)
+// UNI >= 0 (with FULL): the fast instantiations — f = DiagQuadratic, no vector-valued parameters of g or D, the penalties
+// streamed (0), mu a number (1), mu and mu*y = y = 0 numbers (2): every load of the pass is then unconditional too.
+// UNI = -1: run-time everything.
+template <class T, int MM, bool NT, bool FULL = false, int UNI = -1>
+__global__ void __launch_bounds__(BLOCK)
+k_fused_slack_xr(SlackIterates<T, MM> V, CompactCoef<MM> C, ElemParams<T> P, const T* __restrict__ yv, T gamma,
+                 T* __restrict__ xs_d, T* __restrict__ z, int64_t nx, double* __restrict__ parts, int slot0) {
+    constexpr int N = PackN<T>::N;
+    static_assert(UNI < 0 || FULL, "the fast instantiations are for a full memory");
+    const int m = FULL ? MM : V.m;
+    if constexpr (UNI >= 0) { P.f_kind = BZ_F_DIAG_QUADRATIC; P.uni = UNI; }
+    T u1[MM], u2h[MM];
+    compact_coefs<T, MM>(C, u1, u2h);
+    const T H0 = (T)C.H0;
+    const T gl = gamma * P.g_lambda;
+    const T gam0 = (T)C.gam0;
+    // uniform penalties (k_muy's probe): mu is a number, not a stream, and its quotients go through div_u; zero multipliers
+    // as well: mu*y and y are the number 0 (same operands, same operations, same bits as the streamed forms)
+    const bool udiv = P.uni >= 1 && std::is_same<T, double>::value;
+    const T rmu = udiv ? T(1) / P.mu_uniform : T(0);
+    constexpr int NS = 10 + 4 * MM + 2;
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
+        ElemLoads<T> L;
+        Pack<T> dlo, dhi, pyv;
+        if constexpr (UNI >= 0) {
+            L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
+            L.mu = splat(P.mu_uniform); L.muy = splat(T(0)); pyv = splat(T(0));
+            if constexpr (UNI < 1) L.mu = ldp<T, NT>(P.mu, i0, cnt);
+            if constexpr (UNI < 2) { L.muy = ldp<T, NT>(P.muy, i0, cnt); pyv = ldp<T, NT>(yv, i0, cnt); }
+            L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi); L.gu = splat(T(0)); L.glo = splat(P.g_lo); L.ghi = splat(P.g_hi);
+            dlo = L.dlo; dhi = L.dhi;
+        } else {
+            load_params<T, NT>(P, i0, cnt, L, true, true, true);
+            dlo = P.D_lo_vec ? ldp<T, NT>(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
+            dhi = P.D_hi_vec ? ldp<T, NT>(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
+            pyv = P.uni >= 2 ? splat(T(0)) : ldp<T, NT>(yv, i0, cnt);
+        }
+        // the iterates, both halves (h = 0 the x part, h = 1 the s part), and their residuals
+        Pack<T> xh[2][MM + 1], rh[2][MM + 1];
+#pragma unroll
+        for (int i = 0; i <= MM; ++i)
+            if (i <= m) {
+                xh[0][i] = ldp<T, NT>(V.XH[i], i0, cnt);
+                xh[1][i] = ldp<T, NT>(V.XH[i], i0 + nx, cnt);
+            }
+#pragma unroll
+        for (int i = 0; i <= MM; ++i)
+            if (i <= m) {
+                const T gi = (i == 0 && m > 0) ? gam0 : gamma;
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    T zx, zs;
+                    slack_resid(P, xh[0][i].v[e], xh[1][i].v[e], L, e, dlo.v[e], dhi.v[e], pyv.v[e], gi, rh[0][i].v[e], rh[1][i].v[e], zx, zs, udiv, rmu);
+                }
+            }
+        Pack<T> px[2], prp[2], ps[2][MM], py[2][MM], d[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < m) {
+#pragma unroll
+                    for (int e = 0; e < N; ++e) {
+                        ps[h][i].v[e] = xh[h][i + 1].v[e] - xh[h][i].v[e];
+                        py[h][i].v[e] = rh[h][i + 1].v[e] - rh[h][i].v[e];
+                    }
+                }
+            // (the current iterate and its residual: entry m)
+            px[h] = xh[h][0]; prp[h] = rh[h][0];
+#pragma unroll
+            for (int i = 1; i <= MM; ++i)
+                if (i == m) { px[h] = xh[h][i]; prp[h] = rh[h][i]; }
+            compact_d<T, MM>(m, H0, u1, u2h, prp[h], ps[h], py[h], d[h]);
+        }
+        Pack<T> pxd[2], pz[2];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const T xd = px[0].v[e] + d[0].v[e], sd = px[1].v[e] + d[1].v[e];
+            pxd[0].v[e] = xd; pxd[1].v[e] = sd;
+            // grad F(xs_d)   (k_algrad_slack_elem)
+            const SlackOut<T> o1 = slack_elem(P.f_kind, xd, sd, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], pyv.v[e], udiv, rmu);
+            // forward-backward step   (k_fbstep_slack)
+            T t = gamma * o1.gx;
+            const T yx = xd - t;
+            T u = gamma * o1.gs;
+            const T ys = sd - u;
+            T gterm;
+            const T a = prox_elem(P.g_kind, yx, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm);
+            const T b = proj_D(P.D_kind, ys, dlo.v[e], dhi.v[e]);
+            const T r1 = xd - a, r2 = sd - b;
+            pz[0].v[e] = a; pz[1].v[e] = b;
+            // grad F(z)
+            const SlackOut<T> o2 = slack_elem(P.f_kind, a, b, L.q.v[e], L.b.v[e], L.mu.v[e], L.muy.v[e], pyv.v[e], udiv, rmu);
+            // the pair and the stopping norm   (k_update_c)
+            const T sv0 = xd - px[0].v[e], sv1 = sd - px[1].v[e];
+            const T yy0 = r1 - prp[0].v[e], yy1 = r2 - prp[1].v[e];
+            T w0 = r1 / gamma;
+            w0 = w0 - o1.gx;
+            w0 = w0 + o2.gx;
+            T w1 = r2 / gamma;
+            w1 = w1 - o1.gs;
+            w1 = w1 + o2.gs;
+            if (e < cnt) {
+                acc[0] += (double)o1.fterm;
+                acc[1] += (double)o1.pterm;
+                acc[2] += (double)gterm;
+                acc[3] += (double)(o1.gx * r1);
+                acc[3] += (double)(o1.gs * r2);
+                acc[4] += (double)(r1 * r1);
+                acc[4] += (double)(r2 * r2);
+                acc[5] += (double)o2.fterm;
+                acc[6] += (double)o2.pterm;
+                acc[7] += (double)(sv0 * yy0);
+                acc[7] += (double)(sv1 * yy1);
+                acc[8] += (double)(yy0 * yy0);
+                acc[8] += (double)(yy1 * yy1);
+                acc[9] = nanmax(acc[9], (double)(w0 < T(0) ? -w0 : w0));
+                acc[9] = nanmax(acc[9], (double)(w1 < T(0) ? -w1 : w1));
+                const T nr0 = T(-1) * r1, nr1 = T(-1) * r2;
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < m) {
+                        acc[10 + i] = mul_acc(ps[0][i].v[e], yy0, acc[10 + i]);
+                        acc[10 + i] = mul_acc(ps[1][i].v[e], yy1, acc[10 + i]);
+                        acc[10 + MM + i] = mul_acc(py[0][i].v[e], yy0, acc[10 + MM + i]);
+                        acc[10 + MM + i] = mul_acc(py[1][i].v[e], yy1, acc[10 + MM + i]);
+                        acc[10 + 2 * MM + i] = mul_acc(ps[0][i].v[e], nr0, acc[10 + 2 * MM + i]);
+                        acc[10 + 2 * MM + i] = mul_acc(ps[1][i].v[e], nr1, acc[10 + 2 * MM + i]);
+                        acc[10 + 3 * MM + i] = mul_acc(py[0][i].v[e], nr0, acc[10 + 3 * MM + i]);
+                        acc[10 + 3 * MM + i] = mul_acc(py[1][i].v[e], nr1, acc[10 + 3 * MM + i]);
+                    }
+                acc[10 + 4 * MM] = mul_acc(sv0, nr0, acc[10 + 4 * MM]);
+                acc[10 + 4 * MM] = mul_acc(sv1, nr1, acc[10 + 4 * MM]);
+                acc[10 + 4 * MM + 1] = mul_acc(yy0, nr0, acc[10 + 4 * MM + 1]);
+                acc[10 + 4 * MM + 1] = mul_acc(yy1, nr1, acc[10 + 4 * MM + 1]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t o = i0 + (h ? nx : 0);
+            stp<T, NT>(xs_d, o, cnt, pxd[h]);
+            if (z) stp<T, NT>(z, o, cnt, pz[h]);
+        }
+    });
+    if constexpr (NS == 32) block_reduce_store32(acc, 1u << 9, parts, slot0);
+    else block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
+}
+
+// ... and back to stored pairs when an iteration leaves the plain path (a rejected trial point, a skipped pair, a gamma
+// halving): S[i] = XH[i+1] - XH[i], Y[i] = r(XH[i+1]) - r(XH[i]) with r re-evaluated, plus the residual and z of the
+// current iterate (the slack twin of k_pairs_from_iterates; gam[i]: the step size of each iterate's residual)
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_pairs_from_iterates_slack(SnapVecs<T, MM> V, int m, ElemParams<T> P, const T* __restrict__ yv, T* __restrict__ res_cur,
+                            T* __restrict__ z_cur, int64_t nx) {
+    constexpr int N = PackN<T>::N;
+    bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) {
+        const int cnt = cnt_;
+        ElemLoads<T> L;
+        load_params(P, i0, cnt, L, true, true, true);
+        Pack<T> dlo = P.D_lo_vec ? ld(P.D_lo_vec, i0, cnt) : splat(P.D_lo);
+        Pack<T> dhi = P.D_hi_vec ? ld(P.D_hi_vec, i0, cnt) : splat(P.D_hi);
+        Pack<T> pyv = P.uni >= 2 ? splat(T(0)) : ld(yv, i0, cnt);
+        Pack<T> xh[2][MM + 1], rh[2][MM + 1], pz[2];
+#pragma unroll
+        for (int i = 0; i <= MM; ++i) {
+            xh[0][i] = ld(V.XH[i], i0, cnt);
+            xh[1][i] = ld(V.XH[i], i0 + nx, cnt);
+            const T gi = (T)V.gam[i];
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                T zx, zs;
+                slack_resid(P, xh[0][i].v[e], xh[1][i].v[e], L, e, dlo.v[e], dhi.v[e], pyv.v[e], gi, rh[0][i].v[e], rh[1][i].v[e], zx, zs);
+                if (i == MM) { pz[0].v[e] = zx; pz[1].v[e] = zs; }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t o = i0 + (h ? nx : 0);
+#pragma unroll
+            for (int i = 0; i < MM; ++i) {
+                Pack<T> sp, yp;
+#pragma unroll
+                for (int e = 0; e < N; ++e) { sp.v[e] = xh[h][i + 1].v[e] - xh[h][i].v[e]; yp.v[e] = rh[h][i + 1].v[e] - rh[h][i].v[e]; }
+                if (i < m) {
+                    st(V.S[i], o, cnt, sp);
+                    st(V.Y[i], o, cnt, yp);
+                }
+            }
+            st(res_cur, o, cnt, rh[h][MM]);
+            st(z_cur, o, cnt, pz[h]);
+        }
+    });
 }
 
 // ---------------------------------------------------------------------------

@@ -821,6 +821,7 @@ template <class T> class Solver final : public SolverBase {
     int xr_run_ = 0;             // consecutive plain, pair-inserting iterations so far
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
+    int slackfast_env_ = 1;      // BZ_SLACKFAST=0: the slack iterate-history pass always in its run-time-kinds instantiation
     int nt_env_ = -1;            // BZ_NT: -1 (default) non-temporal streams by working-set size, 0 / 1 forced
     int famrt_env_ = 0;          // BZ_FAMRT=1: the headline family through its family-table instantiation (run-time UNI / TRIAL)
     bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
@@ -839,7 +840,12 @@ template <class T> class Solver final : public SolverBase {
             V.gam[i] = back ? gring_[(xc - back + NXR) % NXR] : (double)gamma;
         }
         for (int i = 0; i < m; ++i) { V.S[i] = S_[order[m - 1 - i]].p; V.Y[i] = Y_[order[m - 1 - i]].p; }
-        if (rh_stale_) {
+        if (rh_stale_ && slack) {
+            // (the lifted vector: both halves of every iterate in, both halves of the pairs, the residual and z out)
+            mv(2 * ((m + 1) + 2 * m + 2) + pstreams(true, true, true) + (P.uni >= 2 ? 0 : 1), nx);
+            launch(C_MISC, k_pairs_from_iterates_slack<T, CM>, grid_y, V, m, P, (const T*)ymul_.p, RES_[rc].p, Z_[zc].p, nx);
+            res_valid = true; z_valid = true;
+        } else if (rh_stale_) {
             // (must run before gamma changes: the residuals are re-evaluated with the gamma of this run)
             mv((m + 1) + pstreams(true, true, true) + 2 * m + 2);
             launch(C_MISC, k_pairs_from_iterates<T, CM>, grid, V, m, P, RES_[rc].p, Z_[zc].p, n);
@@ -1801,7 +1807,7 @@ template <class T> class Solver final : public SolverBase {
         // in D, alps.jl:97 scales them alike, and y0 = 0 holds through the first subproblem — the longest one.
         uni_ = 0;
         const int uni_env = std::getenv("BZ_UNI") ? std::atoi(std::getenv("BZ_UNI")) : 2;      // (tests toggle it)
-        const bool probe = uni_env && (fused_family() >= 0 ||
+        const bool probe = uni_env && (fused_family() >= 0 || (slack && !lp_g) ||
                                        (desc.f_kind == BZ_F_STENCIL5 && desc.c_kind == BZ_C_IDENTITY && !slack && !lp_g));
         for (int k = 0; k < 3; ++k) slot_n[SL_GP + k] = grid_y;
         slot_n[SL_OUTER] = slot_n[SL_OUTER + 1] = grid_y;
@@ -2234,6 +2240,7 @@ template <class T> class Solver final : public SolverBase {
         skipz_env_ = std::getenv("BZ_SKIPZ") ? std::atoi(std::getenv("BZ_SKIPZ")) : 1;
         famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
         nt_env_ = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
+        slackfast_env_ = std::getenv("BZ_SLACKFAST") ? std::atoi(std::getenv("BZ_SLACKFAST")) : 1;
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
         // Several ranks: off unless asked for (BZ_GATE=1).  A launch that misses its gate cannot be redone there (the peers
@@ -2528,7 +2535,8 @@ template <class T> class Solver final : public SolverBase {
             // with a partial memory (the absent pairs are x - x = 0 with zero coefficients)
             const int m_now = (int)order.size();
             int xr = 0;
-            if (xr_env_ && small && fam >= 0 && xr_run_ >= m_now) {
+            // (the slack form of ALS has its own iterate-history kernel, k_fused_slack_xr: BZ_XR >= 2, any element-wise kinds)
+            if (xr_env_ && small && (fam >= 0 || slack) && xr_run_ >= m_now) {
                 if (xr_env_ >= 2) xr = 2;
                 else if (headline && m_now == CM && !rh_stale_) xr = 1;
                 // (only the oldest stored iterate may carry another gamma — see CompactCoef::gam0)
@@ -2543,14 +2551,40 @@ template <class T> class Solver final : public SolverBase {
             // SIMD (n = 1e7: 134 vs 140 us; 1.25e6: 28.5 vs 30.2 us): the wave has the vector ALU to itself and
             // the 32-scalar epilogue runs half as often.  (A different grid is a different summation tree: the
             // forms then agree to rounding, not bit for bit — BZ_GFC pins one grid for all of them.)
-            if (xr == 2 && gfc_env <= 0) gfc = std::min(grid, std::max(1, num_cus));
+            if (xr == 2 && gfc_env <= 0 && !slack) gfc = std::min(grid, std::max(1, num_cus));
             for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
             // (the vectors this pass touches: history + x_d + z + the parameter vectors (+ res, s, y))
             const int xr2_streams = (m_now + 1) + pstreams(true, true, true) + 1;      // (pstreams leaves out what travels as numbers)
             const int nvec = (xr == 2 ? xr2_streams : 2 * CM + 5 + pstreams(true, true, true)) + (zstore ? 1 : 0);
             const bool nt = nt_env >= 0 ? nt_env != 0 : (double)n * sizeof(T) * nvec > 340e6;
             if (gate_pending_ && xr != 2) gate_abort();
-            if (xr == 2) {
+            if (xr == 2 && slack) {
+                // the m + 1 last iterates of the lifted vector (both halves), the parameter vectors, y ; xs_d (z) out
+                SlackIterates<T, CM> SV;
+                std::memset(&SV, 0, sizeof(SV));
+                SV.m = m_now;
+                for (int i = 0; i <= m_now; ++i) SV.XH[i] = X_[(xc - (m_now - i) + NXR) % NXR].p;
+                CC.gam0 = gring_[(xc - m_now + NXR) % NXR];
+                const int slack_streams = 2 * (m_now + 1) + pstreams(true, true, true) + (P.uni >= 2 ? 0 : 1) + 2;      // (pstreams counts D's vector bounds)
+                const bool snt = nt_env_ >= 0 ? nt_env_ != 0 : (double)nx * sizeof(T) * (slack_streams + (zstore ? 2 : 0)) > 340e6;
+                mv(slack_streams + (zstore ? 2 : 0), nx);
+                form_[C_FUSED_IT] = std::string("k_fused_slack_xr") + (snt ? "<NT=1>" : "<NT=0>");
+#define BZ_LAUNCH_SXR(NT_, FULL_, UNI_)                                                                            \
+    launch(C_FUSED_IT, k_fused_slack_xr<T, CM, NT_, FULL_, UNI_>, gfc, SV, CC, P, (const T*)ymul_.p, gamma, X_[xd].p, zstore, nx, \
+           parts_.p, (int)SL_TRIAL)
+                // (the fast instantiations: a full memory, f = DiagQuadratic, no vector-valued parameters of g or D)
+                const bool fast = slackfast_env_ && m_now == CM && desc.f_kind == BZ_F_DIAG_QUADRATIC && pstreams(false, true, true) == 2 - std::min(2, (int)P.uni) &&
+                                  !(P.g_u && (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX));
+                if (fast) {
+                    form_[C_FUSED_IT] += "(fast)";
+                    if (snt) { if (P.uni >= 2) BZ_LAUNCH_SXR(true, true, 2); else if (P.uni == 1) BZ_LAUNCH_SXR(true, true, 1); else BZ_LAUNCH_SXR(true, true, 0); }
+                    else { if (P.uni >= 2) BZ_LAUNCH_SXR(false, true, 2); else if (P.uni == 1) BZ_LAUNCH_SXR(false, true, 1); else BZ_LAUNCH_SXR(false, true, 0); }
+                } else if (m_now == CM) { if (snt) BZ_LAUNCH_SXR(true, true, -1); else BZ_LAUNCH_SXR(false, true, -1); }
+                else { if (snt) BZ_LAUNCH_SXR(true, false, -1); else BZ_LAUNCH_SXR(false, false, -1); }
+#undef BZ_LAUNCH_SXR
+                sy_stale_ = true; rh_stale_ = true; res_skipped = true;
+                trial_ok = false;      // (a tau-backtracked point finishes in the generic chain, after the pairs are re-materialised)
+            } else if (xr == 2) {
                 CompactVecs<T, CM> XV;
                 XV.m = CM;
                 for (int i = 0; i < CM; ++i) {
@@ -2606,7 +2640,7 @@ template <class T> class Solver final : public SolverBase {
             if (slack) {
                 // the lifted vector [x; s]: res, S[m], Y[m], xs ; xs_d, res, s_new, y_new (z) — both halves — and over n the
                 // parameter vectors and the multipliers y
-                mv(2 * (2 + 2 * CV.m + 4 + (zstore ? 1 : 0)) + pstreams(true, true, true) + 1, nx);
+                mv(2 * (2 + 2 * CV.m + 4 + (zstore ? 1 : 0)) + pstreams(true, true, true) + (P.uni >= 2 ? 0 : 1), nx);
                 form_[C_FUSED] = std::string("k_fused_slack") + (nt ? "<NT=1>" : "<NT=0>");
                 if (nt)
                     launch(C_FUSED, k_fused_slack<T, CM, true>, gfc, CV, CC, (const T*)X_[xp].p, (const T*)RES_[rp].p, P,

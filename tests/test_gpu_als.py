@@ -111,7 +111,10 @@ def test_fused_slack_pass_follows_the_kernel_chain(bz, ref, n, D):
         prob.close()
     (ta, sa, pa), (tb, sb, pb) = runs
     assert sa.n_fused_iters >= 30 and sb.n_fused_iters == 0
-    assert pa["k_fused_sep"]["form"].startswith("k_fused_slack") and pa["k_fused_sep"]["launches"] >= 30
+    # (the iterate-history pass from the first iteration on — an empty memory is m = 0 iterates behind the current one; the
+    # stored-pair pass k_fused_slack only after a broken run of plain iterations)
+    assert pa["k_fused_iterates"]["form"].startswith("k_fused_slack_xr")
+    assert pa["k_fused_sep"]["launches"] + pa["k_fused_iterates"]["launches"] >= 30 and pa["k_fused_iterates"]["launches"] >= 20
     for (xa, ca), (xb, cb) in zip(ta, tb):
         assert ca["gamma"] == cb["gamma"] and ca["lbfgs_mem"] == cb["lbfgs_mem"]
         assert np.max(np.abs(xa - xb)) <= 1e-10 * max(1.0, np.max(np.abs(xb)))
@@ -222,3 +225,89 @@ def test_als_with_zero_smooth_cost_terminates_like_the_reference(bz, ref, g, D):
     z, st = prob.panoc_solve(bz.PANOCplus(tol=1e-8, maxit=50).c_opts(), np.concatenate([x0, x0]))
     assert st.iters == 50 and not np.isfinite(st.gamma)
     prob.close()
+
+
+@pytest.mark.parametrize("D,g", [("box", "l1"), ("free", "l1box"), ("zero", "nonneg")])
+@pytest.mark.parametrize("n,iters,start", [(30_010, 150, "random"), (400_002, 60, "random"), (100_002, 300, "zero")])
+def test_slack_iterate_history_form_is_bitwise_neutral(bz, ref, n, iters, start, D, g, monkeypatch):
+    """ALS in the iterate-history form (k_fused_slack_xr: the m + 1 last iterates of [x; s] in, their residuals re-evaluated
+    in registers, xs_d out — 1.5 GB per iteration at n = 1e7 instead of 2.96) against the stored-pair pass (k_fused_slack)
+    on one grid: the same bits in x, z, res and every scalar, through tau backtracks, gamma halvings and skipped pairs
+    (where the pairs are re-materialised from the iterates, k_pairs_from_iterates_slack), with z stored or kept in
+    registers (auglagfunslack.jl:78-97,136-154)."""
+    d, dev, orc = make_cfg2(bz, ref, n, D=D, g=g)
+    rng = np.random.default_rng(n % 1000 + 3)
+    mu = 10.0 ** rng.uniform(-1.5, -0.5, n)
+    y = 0.5 * rng.standard_normal(n)
+    xs0 = np.zeros(2 * n) if start == "zero" else np.concatenate([0.3 * rng.standard_normal(n), 0.3 * rng.standard_normal(n)])
+    pin = {"BZ_GFC": "2", "BZ_GRID": "512"}
+    runs = {}
+    for name, env in (("pairs", dict(pin, BZ_XR="0")), ("iterates", dict(pin, BZ_XR="2")), ("iterates-z", dict(pin, BZ_XR="2", BZ_SKIPZ="0")),
+                      ("iterates-nt", dict(pin, BZ_XR="2", BZ_NT="1")), ("iterates-generic", dict(pin, BZ_XR="2", BZ_SLACKFAST="0"))):
+        for k in ("BZ_XR", "BZ_SKIPZ", "BZ_NT", "BZ_GFC", "BZ_GRID", "BZ_SLACKFAST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        prob = bz.Problem(*dev, n, n, np.float64, slack=True)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps)).c_opts(), xs0)
+        for _ in range(iters):
+            prob.panoc_step()
+        st = prob.panoc_stats()
+        p = prob.profile2()
+        runs[name] = (prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars(),
+                      (st.n_backtracks, st.n_gamma_halvings, st.n_lbfgs_skips, st.n_fused_iters, st.n_grad, st.n_prox),
+                      p["k_fused_iterates"]["launches"], p["k_fused_iterates"]["form"])
+        prob.close()
+    base = runs["pairs"]
+    assert base[5] == 0
+    for name in ("iterates", "iterates-z", "iterates-nt", "iterates-generic"):
+        r = runs[name]
+        assert r[5] >= max(4, iters - 12 - 7 * base[4][2] - 2 * base[4][0] - base[4][1]), (name, r[5], base[4])
+        assert r[6].startswith("k_fused_slack_xr<NT=1>" if name == "iterates-nt" else "k_fused_slack_xr<NT=0>"), r[6]
+        # (the compile-time instantiations serve f = DiagQuadratic without vector-valued parameters: NormL1Box's u is one)
+        assert r[6].endswith("(fast)") == (g != "l1box" and name != "iterates-generic"), (name, r[6])
+        for a, b in zip(r[:3], base[:3]):
+            assert np.array_equal(a, b), name
+        for key in ("k", "gamma", "tau", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_mem", "lbfgs_H", "FBE"):
+            assert r[3][key] == base[3][key], (name, key)
+        assert r[4][:3] == base[4][:3]
+
+
+@pytest.mark.parametrize("yzero", [True, False])
+def test_slack_uniform_penalties_travel_as_numbers_bitwise(bz, ref, yzero, monkeypatch):
+    """alps.jl:42 / als.jl:45 give every constraint the same mu whenever c(x0) is in D, and y0 = 0 holds through the first
+    subproblem: the slack passes then take mu (and mu*y = y = 0) as NUMBERS — two or three streams fewer — and the
+    quotients by mu through two Markstein steps (div_u).  Same operands, same operations: BZ_UNI=0 (everything streamed,
+    hardware division) gives the same bits, in both forms of the history."""
+    n = 120_002
+    d, dev, orc = make_cfg2(bz, ref, n, D="box", g="l1")
+    rng = np.random.default_rng(17)
+    mu = np.full(n, 0.1)
+    y = np.zeros(n) if yzero else 0.5 * rng.standard_normal(n)
+    xs0 = np.concatenate([0.3 * rng.standard_normal(n), 0.3 * rng.standard_normal(n)])
+    outs = {}
+    for uni in ("0", "2"):
+        for xr in ("0", "2"):
+            monkeypatch.setenv("BZ_UNI", uni); monkeypatch.setenv("BZ_XR", xr)
+            monkeypatch.setenv("BZ_GFC", "2"); monkeypatch.setenv("BZ_GRID", "512")
+            prob = bz.Problem(*dev, n, n, np.float64, slack=True)
+            prob.set_multipliers(mu, y)
+            prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(float).eps)).c_opts(), xs0)
+            prob.profile_reset()
+            prob.profile_enable(True)
+            for _ in range(60):
+                prob.panoc_step()
+            p = prob.profile2()
+            cat = "k_fused_iterates" if xr == "2" else "k_fused_sep"
+            outs[(uni, xr)] = (prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_scalars(),
+                               p[cat]["bytes"] / max(1, p[cat]["launches"]) / (8.0 * n))
+            prob.close()
+    base = outs[("0", "0")]
+    for key, r in outs.items():
+        assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]), key
+        for k in ("gamma", "f_x", "g_z", "stop_norm", "last_ys", "lbfgs_H", "FBE"):
+            assert r[2][k] == base[2][k], (key, k)
+    # streams per launch of the iterate-history pass at m = 5: 12 iterate halves + q, b (+ mu, mu*y, y) + 2 out (+ 2 with z)
+    saved = 3 if yzero else 1
+    assert outs[("0", "2")][3] - outs[("2", "2")][3] >= saved - 0.5

@@ -1421,8 +1421,11 @@ __device__ __forceinline__ void dense_wait_tile(typename PackVec<T>::type (&ring
         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ring[BI][0][0]), "+v"(ring[BI][1][0]) : "n"(CNT) : "memory");
 }
 
+// (no minimum-occupancy launch bound for the narrow forms: a register cap makes the compiler SPILL ring registers right behind
+// their asm loads — it believes them defined — and a spilled register is stored before its data has arrived;
+// tools/check_dense_ring.py checks every instantiation for spill code)
 template <class T, int KP>
-__global__ void __launch_bounds__(FBLOCK, 2 * (16 / (int)sizeof(T)) / KP)
+__global__ void __launch_bounds__(FBLOCK)
 k_dense_fused(DenseFusedArgs<T> a, ElemParams<T> P) {
     constexpr int N = PackN<T>::N;
     __shared__ double sh_w[2][FWAVES][FT];      // (by step parity: a wave may write the next step's before a late one has read this step's)

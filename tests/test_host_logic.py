@@ -222,3 +222,16 @@ def test_profile_forms_are_reproducible_from_kernel_names():
     assert sp.form_of("bz::k_stencil_fb<double, true>") == "k_stencil_fb<NT=1>"
     assert sp.form_of("bz::k_fused_compact<double, 5, true, true, true, 2, 2, 0, 39>") == "k_fused_compact<XR=2,UNI=2,NT=1,TRIAL=0,FAM=39>"
     assert sp.form_of("bz::k_fused_compact<double, 5, true, true, true, 2, 2, 0, 35>") == "k_fused_compact<XR=2,UNI=2,NT=1,TRIAL=0>"
+
+
+def test_dense_ring_kernel_has_no_spill_code_and_exact_waits():
+    """k_dense_fused loads its register ring with inline asm (the compiler's own wait bookkeeping drained the prefetch): a
+    spilled ring register would be stored before its data has arrived.  tools/check_dense_ring.py compiles every
+    instantiation for gfx950 (no GPU needed) and checks for spill code and for the ring waits' counts."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dense_ring.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count(" 0 findings") == 5, r.stdout

@@ -1,6 +1,6 @@
 #!/bin/bash
-# after `gpurun -- 'bash tools/run_round_benches.sh r02'`: summaries + bench lines into profiles/
-tag=${1:-r02}
+# after `gpurun -- 'bash tools/run_round_benches.sh r03'` (and `... r03 prof`): summaries + bench lines into profiles/
+tag=${1:-r03}
 cmd="python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras"
 python tools/summarize_profiles.py --tag $tag --workload cfg2 --n 10000000 --stats gpurun_out/prof_cfg2/stats --fetch gpurun_out/prof_cfg2/fetch --write gpurun_out/prof_cfg2/write --command "$cmd"
 python tools/summarize_profiles.py --tag $tag --workload cfg3 --n 4194304 --stats gpurun_out/prof_cfg3/stats --fetch gpurun_out/prof_cfg3/fetch --write gpurun_out/prof_cfg3/write --command "$cmd --workload cfg3"

@@ -1,8 +1,8 @@
 #!/bin/bash
 # All bench lines (+ profiles with "prof") of a round on the GPU box:
-#   gpurun -- 'bash tools/run_round_benches.sh r02'          the bench lines
-#   gpurun -- 'bash tools/run_round_benches.sh r02 prof'     the rocprofv3 kernel statistics + PMC traffic
-tag=${1:-r02}
+#   gpurun -- 'bash tools/run_round_benches.sh r03'          the bench lines
+#   gpurun -- 'bash tools/run_round_benches.sh r03 prof'     the rocprofv3 kernel statistics + PMC traffic
+tag=${1:-r03}
 o=gpurun_out/$tag
 mkdir -p $o
 if [ "$2" = "prof" ]; then

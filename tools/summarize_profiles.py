@@ -66,6 +66,12 @@ def form_of(kernel):
     m = re.match(r"(k_compact_xd|k_stencil_update_c)<\w+, \d+(?:, (true|false), (true|false))?>$", k)
     if m:
         return f"{m.group(1)}<FULL={int(m.group(2) == 'true')},NT={int(m.group(3) == 'true')}>"
+    m = re.match(r"k_dense_fused<\w+, (\d+)>$", k)
+    if m:
+        return f"k_dense_fused<KP={m.group(1)}>"
+    m = re.match(r"k_fused_slack_xr<\w+, \d+, (true|false), (true|false), (-?\d+)>$", k)
+    if m:      # (the fast instantiations — compile-time UNI >= 0 — are reported with a "(fast)" suffix: bz_solver.hip)
+        return f"k_fused_slack_xr<NT={int(m.group(1) == 'true')}>" + ("(fast)" if int(m.group(3)) >= 0 else "")
     m = re.match(r"k_fused_slack<\w+, \d+, (true|false)>$", k)
     if m:
         return f"k_fused_slack<NT={int(m.group(1) == 'true')}>"

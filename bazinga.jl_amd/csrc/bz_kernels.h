@@ -342,30 +342,30 @@ template <class T> __device__ __forceinline__ T min0(T x) { return (x < T(0) || 
 // The pairwise sets: this element's component of the projection of the pair (x1, x2); `pos` says which
 // component this element is (0: x1 = t, x2 = tp ; 1: x1 = tp, x2 = t).
 template <class T> __device__ __forceinline__ T proj_pair(int kind, T t, T tp, int pos) {
+    // Each kind as ONE keep-or-zero decision per component, built from ordered compares of the pair (the reference's
+    // branch ladders, flattened: every path returns either the component itself or the literal zero, so the ladder is a
+    // predicate).  A NaN component fails every ordered compare exactly as it falls through the reference's ifs.
     const T x1 = pos ? tp : t, x2 = pos ? t : tp;
-    T z1, z2;
+    bool keep;
     if (kind == BZ_D_VC_PAIRS) {              // vanishingConstraints.jl:27-46  (x1 >= 0, x1*x2 >= 0)
-        z1 = T(0); z2 = T(0);
-        if (x1 <= T(0)) { z2 = x2; }
-        else if (x2 >= T(0)) { z1 = x1; z2 = x2; }
-        else if (x1 + x2 > T(0)) { z1 = x1; }
-        else { z2 = x2; }                     // x1 + x2 < 0, and the set-valued tie x1 + x2 = 0
+        // x1 <= 0 -> (0, x2) ; x2 >= 0 -> (x1, x2) ; x1 + x2 > 0 -> (x1, 0) ; else (the tie x1 + x2 = 0 too) (0, x2)
+        const bool a = x1 <= T(0), b = x2 >= T(0), c = x1 + x2 > T(0);
+        keep = pos ? (a || b || !c) : (!a && (b || c));
     } else if (kind == BZ_D_CC_PAIRS) {       // complementarityConstraints.jl:8-20
-        if (x1 > T(0) && x2 > T(0)) {
-            z1 = x1; z2 = x2;
-            if (x2 > x1) z1 = T(0); else z2 = T(0);
-        } else { z1 = max0(x1); z2 = max0(x2); }
+        // both > 0: the larger one stays (x1 on a tie) ; otherwise max(0, .) of each: a component stays iff it is not
+        // <= 0 (NaN stays) and the other one does not beat it
+        keep = pos ? (!(x2 <= T(0)) && !(x1 >= x2)) : (!(x1 <= T(0)) && !(x2 > x1));
     } else if (kind == BZ_D_EITHEROR_PAIRS) { // orConstraints.jl:7-17
-        z1 = x1; z2 = x2;
-        if (x1 < T(0) && x2 < T(0)) { if (x1 > x2) z1 = T(0); else z2 = T(0); }
+        // both < 0: the larger one is zeroed (x2 on a tie)
+        const bool both = x1 < T(0) && x2 < T(0), g = x1 > x2;
+        keep = pos ? !(both && !g) : !(both && g);
     } else {                                  // XOR, orConstraints.jl:24-36
-        z1 = x1; z2 = x2;
-        if (x1 * x2 > T(0)) {
-            if (x1 > x2) { z1 = max0(x1); z2 = min0(x2); }
-            else { z1 = min0(x1); z2 = max0(x2); }
-        }
+        // x1 x2 > 0 (same sign, product not underflown): x1 > x2 -> (max(0,x1), min(0,x2)) else (min(0,x1), max(0,x2)):
+        // of two positives the smaller is zeroed, of two negatives the larger (x1 on a tie of positives, x2 of negatives)
+        const bool same = x1 * x2 > T(0), g = x1 > x2;
+        keep = pos ? !(same && (g == (x2 > T(0)))) : !(same && (g != (x1 > T(0))));
     }
-    return pos ? z2 : z1;
+    return keep ? t : T(0);
 }
 
 // tp / pos: the pair partner's argument and this element's position, used by the pairwise kinds only

@@ -972,6 +972,35 @@ def test_pairwise_sets_al_gradient_bit_exact(bz, ref, n, kind):
     prob.close()
 
 
+@pytest.mark.parametrize("kind", ["vc", "cc", "eitheror", "xor"])
+def test_pairwise_sets_every_special_pair_bit_exact(bz, ref, kind):
+    """The device evaluates the pairwise projections as one keep-or-zero predicate per component (`proj_pair`,
+    bz_kernels.h) where the reference walks a ladder of ifs (vanishingConstraints.jl:27-46,
+    complementarityConstraints.jl:8-20, orConstraints.jl:7-36).  EVERY ordered pair of the values where the ladders
+    branch — zeros of either sign, equal and opposite magnitudes (the ties), numbers whose product underflows (XOR tests
+    x1*x2 > 0), a denormal, infinities, NaN — in both slots, through `gradient!` with mu = 1, y = 0, f = Zero (so
+    dlx = x - proj_D(x): the keep-or-zero decision itself, sign of the zero included): the bits of the oracle."""
+    sp = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 2.0, -2.0, 1e-200, -1e-200, 5e-324, -5e-324, 1e300, -1e300,
+                   np.inf, -np.inf, np.nan])
+    a, b = np.meshgrid(sp, sp, indexing="ij")
+    x = np.stack([a.ravel(), b.ravel()], axis=1).ravel().copy()          # (x1, x2) adjacent: every ordered pair once
+    n = x.size
+    dev = (bz.Zero(), bz.Zero(), bz.IdentityFunction(), bz.PairwiseSet(kind))
+    orc = (ref.Zero(), ref.Zero(), ref.IdentityFunction(), ref.PairwiseSet(kind))
+    prob = bz.Problem(*dev, n, n, np.float64)
+    prob.set_multipliers(np.ones(n), np.zeros(n))
+    g_dev, _ = prob.eval_al_gradient(x)
+    al = ref.AugLagFun(orc[0], orc[2], orc[3], np.ones(n), np.zeros(n), x)
+    g_ref = np.empty(n)
+    with np.errstate(all="ignore"):
+        al.gradient(g_ref, x)
+    nan_d, nan_r = np.isnan(g_dev), np.isnan(g_ref)
+    assert np.array_equal(nan_d, nan_r), np.flatnonzero(nan_d != nan_r)[:10]
+    bad = np.flatnonzero((g_dev.view(np.uint64) != g_ref.view(np.uint64)) & ~nan_d)
+    assert bad.size == 0, [(x[i - i % 2], x[i - i % 2 + 1], i % 2, g_dev[i], g_ref[i]) for i in bad[:8]]
+    prob.close()
+
+
 @pytest.mark.parametrize("kind,g", [("vc", "zero"), ("cc", "l1"), ("eitheror", "zero"), ("xor", "l1")])
 def test_pairwise_sets_alps(bz, ref, kind, g):
     """Whole ALPS solves with a pairwise (nonconvex) D: same outer/inner counts and solution as the oracle,

@@ -3323,14 +3323,19 @@ __device__ __forceinline__ void slack_resid(const ElemParams<T>& P, T x, T sv, c
 // UNI >= 0 (with FULL): the fast instantiations — f = DiagQuadratic, no vector-valued parameters of g or D, the penalties
 // streamed (0), mu a number (1), mu and mu*y = y = 0 numbers (2): every load of the pass is then unconditional too.
 // UNI = -1: run-time everything.
-template <class T, int MM, bool NT, bool FULL = false, int UNI = -1>
+// KIND = 1 (fast only): g = NormL1 and D = Box as compile-time facts too (the ALS form of cfg 2: with run-time kinds the
+// seven evaluations of prox_g / proj_D per index are ladders of wave-uniform branches, a third of the pass's instructions).
+// DEPTH: packs of loads kept in flight ahead of the one being consumed (0: none, the loads of a pack issue at its start).
+template <class T, int MM, bool NT, bool FULL = false, int UNI = -1, int KIND = 0, int DEPTH = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_fused_slack_xr(SlackIterates<T, MM> V, CompactCoef<MM> C, ElemParams<T> P, const T* __restrict__ yv, T gamma,
                  T* __restrict__ xs_d, T* __restrict__ z, int64_t nx, double* __restrict__ parts, int slot0) {
     constexpr int N = PackN<T>::N;
     static_assert(UNI < 0 || FULL, "the fast instantiations are for a full memory");
     const int m = FULL ? MM : V.m;
+    static_assert((KIND == 0 && DEPTH == 0) || UNI >= 0, "compile-time kinds and the pipeline belong to the fast instantiations");
     if constexpr (UNI >= 0) { P.f_kind = BZ_F_DIAG_QUADRATIC; P.uni = UNI; }
+    if constexpr (KIND == 1) { P.g_kind = BZ_G_NORM_L1; P.D_kind = BZ_D_BOX; }
     T u1[MM], u2h[MM];
     compact_coefs<T, MM>(C, u1, u2h);
     const T H0 = (T)C.H0;
@@ -3344,10 +3349,38 @@ k_fused_slack_xr(SlackIterates<T, MM> V, CompactCoef<MM> C, ElemParams<T> P, con
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-    bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) {
+    // The fast instantiations run a software pipeline in registers, two packs ahead (the headline kernel's, k_fused_compact):
+    // the 14-17 loads of the thread's NEXT pack — every stream as scalar base + ONE shared 32-bit offset — are issued before
+    // this pack's ~1500 instructions run, so a wave always has a full pack of loads in flight.  Needs nx * sizeof(T) < 4 GiB.
+    constexpr bool PIPE = DEPTH > 0;
+    struct Stage { Pack<T> q, b, mu, muy, yv, xh[2][MM + 1]; };
+    auto load_stage = [&](Stage& S, unsigned bo) {
+        asm volatile("" : "+v"(bo));
+        S.q = ldo<T, NT>(P.q, bo); S.b = ldo<T, NT>(P.b, bo);
+        if constexpr (UNI < 1) S.mu = ldo<T, NT>(P.mu, bo);
+        if constexpr (UNI < 2) { S.muy = ldo<T, NT>(P.muy, bo); S.yv = ldo<T, NT>(yv, bo); }
+#pragma unroll
+        for (int i = 0; i <= MM; ++i) {
+            S.xh[0][i] = ldo<T, NT>(V.XH[i], bo);
+            S.xh[1][i] = ldo<T, NT>(V.XH[i] + nx, bo);
+        }
+    };
+    auto body = [&](const int64_t i0, const auto cnt_, const auto staged_, const Stage& SG) {
         const int cnt = cnt_;      // compile-time PackN in the main loop, run-time only for the ragged last chunk
+        constexpr bool STAGED = std::remove_cv_t<decltype(staged_)>::value;
         ElemLoads<T> L;
         Pack<T> dlo, dhi, pyv;
+        Pack<T> xh[2][MM + 1], rh[2][MM + 1];
+        if constexpr (STAGED) {
+            L.q = SG.q; L.b = SG.b;
+            L.mu = splat(P.mu_uniform); L.muy = splat(T(0)); pyv = splat(T(0));
+            if constexpr (UNI < 1) L.mu = SG.mu;
+            if constexpr (UNI < 2) { L.muy = SG.muy; pyv = SG.yv; }
+            L.dlo = splat(P.D_lo); L.dhi = splat(P.D_hi); L.gu = splat(T(0)); L.glo = splat(P.g_lo); L.ghi = splat(P.g_hi);
+            dlo = L.dlo; dhi = L.dhi;
+#pragma unroll
+            for (int i = 0; i <= MM; ++i) { xh[0][i] = SG.xh[0][i]; xh[1][i] = SG.xh[1][i]; }
+        } else {
         if constexpr (UNI >= 0) {
             L.q = ldp<T, NT>(P.q, i0, cnt); L.b = ldp<T, NT>(P.b, i0, cnt);
             L.mu = splat(P.mu_uniform); L.muy = splat(T(0)); pyv = splat(T(0));
@@ -3362,13 +3395,13 @@ k_fused_slack_xr(SlackIterates<T, MM> V, CompactCoef<MM> C, ElemParams<T> P, con
             pyv = P.uni >= 2 ? splat(T(0)) : ldp<T, NT>(yv, i0, cnt);
         }
         // the iterates, both halves (h = 0 the x part, h = 1 the s part), and their residuals
-        Pack<T> xh[2][MM + 1], rh[2][MM + 1];
 #pragma unroll
         for (int i = 0; i <= MM; ++i)
             if (i <= m) {
                 xh[0][i] = ldp<T, NT>(V.XH[i], i0, cnt);
                 xh[1][i] = ldp<T, NT>(V.XH[i], i0 + nx, cnt);
             }
+        }
 #pragma unroll
         for (int i = 0; i <= MM; ++i)
             if (i <= m) {
@@ -3463,11 +3496,52 @@ k_fused_slack_xr(SlackIterates<T, MM> V, CompactCoef<MM> C, ElemParams<T> P, con
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int64_t o = i0 + (h ? nx : 0);
-            stp<T, NT>(xs_d, o, cnt, pxd[h]);
-            if (z) stp<T, NT>(z, o, cnt, pz[h]);
+            if constexpr (STAGED) {
+                unsigned bo = (unsigned)(i0 * (int64_t)sizeof(T));
+                asm volatile("" : "+v"(bo));
+                sto<T, NT>(h ? xs_d + nx : xs_d, bo, pxd[h]);
+                if (z) sto<T, NT>(h ? z + nx : z, bo, pz[h]);
+            } else {
+                const int64_t o = i0 + (h ? nx : 0);
+                stp<T, NT>(xs_d, o, cnt, pxd[h]);
+                if (z) stp<T, NT>(z, o, cnt, pz[h]);
+            }
         }
-    });
+    };
+    if constexpr (PIPE) {
+        // the chunk -> thread map of bz_for_chunks (so the sums are those of every other form on this grid, bit for bit); past
+        // the end a thread re-requests the last full chunk: no branch around a load, nothing out of bounds
+        const int64_t nfull = nx / N;
+        const int64_t stride = (int64_t)gridDim.x * BLOCK;
+        int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        auto fetch = [&](Stage& S, int64_t k) { load_stage(S, (unsigned)((k < nfull ? k : nfull - 1) * N * (int64_t)sizeof(T))); };
+        auto use = [&](const Stage& S, int64_t k) { body(k * N, std::integral_constant<int, N>{}, std::true_type{}, S); };
+        Stage sa, sb;
+        if constexpr (DEPTH == 2) {
+            Stage sc;
+            if (c < nfull) { fetch(sa, c); fetch(sb, c + stride); }
+            for (;;) {      // three stages in rotation, the loop unrolled by three: no register copies between iterations
+                if (c >= nfull) break;
+                fetch(sc, c + 2 * stride); use(sa, c); c += stride;
+                if (c >= nfull) break;
+                fetch(sa, c + 2 * stride); use(sb, c); c += stride;
+                if (c >= nfull) break;
+                fetch(sb, c + 2 * stride); use(sc, c); c += stride;
+            }
+        } else {
+            if (c < nfull) fetch(sa, c);
+            for (;;) {
+                if (c >= nfull) break;
+                fetch(sb, c + stride); use(sa, c); c += stride;
+                if (c >= nfull) break;
+                fetch(sa, c + stride); use(sb, c); c += stride;
+            }
+        }
+        if (c == nfull && nfull * N < nx) body(c * N, (int)(nx - nfull * N), std::false_type{}, sa);
+    } else {
+        Stage none;
+        bz_for_chunks<T>(nx, [&](const int64_t i0, const auto cnt_) { body(i0, cnt_, std::false_type{}, none); });
+    }
     if constexpr (NS == 32) block_reduce_store32(acc, 1u << 9, parts, slot0);
     else block_reduce_store<NS>(acc, 1u << 9, parts, slot0);
 }

@@ -822,6 +822,8 @@ template <class T> class Solver final : public SolverBase {
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
     int slackfast_env_ = 1;      // BZ_SLACKFAST=0: the slack iterate-history pass always in its run-time-kinds instantiation
+    int slackkind_env_ = 1;      // BZ_SLACKKIND=0: its fast instantiations with run-time kinds of g and D
+    int slackdepth_env_ = 1;     // BZ_SLACKDEPTH=0: ... without the one-pack-ahead register pipeline (232 against 227 us per pass)
     int nt_env_ = -1;            // BZ_NT: -1 (default) non-temporal streams by working-set size, 0 / 1 forced
     int famrt_env_ = 0;          // BZ_FAMRT=1: the headline family through its family-table instantiation (run-time UNI / TRIAL)
     bool sy_stale_ = false;      // S_/Y_ do not hold the stored pairs (they live in the rings)
@@ -2241,6 +2243,8 @@ template <class T> class Solver final : public SolverBase {
         famrt_env_ = std::getenv("BZ_FAMRT") ? std::atoi(std::getenv("BZ_FAMRT")) : 0;
         nt_env_ = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
         slackfast_env_ = std::getenv("BZ_SLACKFAST") ? std::atoi(std::getenv("BZ_SLACKFAST")) : 1;
+        slackkind_env_ = std::getenv("BZ_SLACKKIND") ? std::atoi(std::getenv("BZ_SLACKKIND")) : 1;
+        slackdepth_env_ = std::getenv("BZ_SLACKDEPTH") ? std::atoi(std::getenv("BZ_SLACKDEPTH")) : 1;
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
         // Several ranks: off unless asked for (BZ_GATE=1).  A launch that misses its gate cannot be redone there (the peers
@@ -2551,7 +2555,14 @@ template <class T> class Solver final : public SolverBase {
             // SIMD (n = 1e7: 134 vs 140 us; 1.25e6: 28.5 vs 30.2 us): the wave has the vector ALU to itself and
             // the 32-scalar epilogue runs half as often.  (A different grid is a different summation tree: the
             // forms then agree to rounding, not bit for bit — BZ_GFC pins one grid for all of them.)
-            if (xr == 2 && gfc_env <= 0 && !slack) gfc = std::min(grid, std::max(1, num_cus));
+            // (the slack form's fast instantiations: a full memory, f = DiagQuadratic, no vector-valued parameters of g or D —
+            // pipelined like the headline kernel, 256 VGPRs + spill AGPRs: one workgroup per CU there too)
+            const bool slack_fast = slack && xr == 2 && slackfast_env_ && m_now == CM && desc.f_kind == BZ_F_DIAG_QUADRATIC &&
+                                    pstreams(false, true, true) == 2 - std::min(2, (int)P.uni) &&
+                                    !(P.g_u && (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX));
+            // ... with the kinds fixed too (g = NormL1, D = Box: the ALS form of cfg 2), one pack of loads ahead
+            const bool slack_hk = slack_fast && slackkind_env_ && P.g_kind == BZ_G_NORM_L1 && P.D_kind == BZ_D_BOX;
+            if (xr == 2 && gfc_env <= 0 && (!slack || (slack_hk && slackdepth_env_ > 0))) gfc = std::min(grid, std::max(1, num_cus));
             for (int k = 0; k < NFC; ++k) slot_n[SL_TRIAL + k] = gfc;
             // (the vectors this pass touches: history + x_d + z + the parameter vectors (+ res, s, y))
             const int xr2_streams = (m_now + 1) + pstreams(true, true, true) + 1;      // (pstreams leaves out what travels as numbers)
@@ -2569,18 +2580,24 @@ template <class T> class Solver final : public SolverBase {
                 const bool snt = nt_env_ >= 0 ? nt_env_ != 0 : (double)nx * sizeof(T) * (slack_streams + (zstore ? 2 : 0)) > 340e6;
                 mv(slack_streams + (zstore ? 2 : 0), nx);
                 form_[C_FUSED_IT] = std::string("k_fused_slack_xr") + (snt ? "<NT=1>" : "<NT=0>");
-#define BZ_LAUNCH_SXR(NT_, FULL_, UNI_)                                                                            \
-    launch(C_FUSED_IT, k_fused_slack_xr<T, CM, NT_, FULL_, UNI_>, gfc, SV, CC, P, (const T*)ymul_.p, gamma, X_[xd].p, zstore, nx, \
+#define BZ_LAUNCH_SXR(NT_, FULL_, UNI_, KIND_, DEPTH_)                                                             \
+    launch(C_FUSED_IT, k_fused_slack_xr<T, CM, NT_, FULL_, UNI_, KIND_, DEPTH_>, gfc, SV, CC, P, (const T*)ymul_.p, gamma, X_[xd].p, zstore, nx, \
            parts_.p, (int)SL_TRIAL)
+#define BZ_LAUNCH_SXR_U(NT_, KIND_, DEPTH_)                                                                        \
+    do { if (P.uni >= 2) BZ_LAUNCH_SXR(NT_, true, 2, KIND_, DEPTH_); else if (P.uni == 1) BZ_LAUNCH_SXR(NT_, true, 1, KIND_, DEPTH_); \
+         else BZ_LAUNCH_SXR(NT_, true, 0, KIND_, DEPTH_); } while (0)
                 // (the fast instantiations: a full memory, f = DiagQuadratic, no vector-valued parameters of g or D)
-                const bool fast = slackfast_env_ && m_now == CM && desc.f_kind == BZ_F_DIAG_QUADRATIC && pstreams(false, true, true) == 2 - std::min(2, (int)P.uni) &&
-                                  !(P.g_u && (P.g_kind == BZ_G_NORM_L1_BOX || P.g_kind == BZ_G_NORM_L0_BOX));
+                const bool fast = slack_fast;
                 if (fast) {
-                    form_[C_FUSED_IT] += "(fast)";
-                    if (snt) { if (P.uni >= 2) BZ_LAUNCH_SXR(true, true, 2); else if (P.uni == 1) BZ_LAUNCH_SXR(true, true, 1); else BZ_LAUNCH_SXR(true, true, 0); }
-                    else { if (P.uni >= 2) BZ_LAUNCH_SXR(false, true, 2); else if (P.uni == 1) BZ_LAUNCH_SXR(false, true, 1); else BZ_LAUNCH_SXR(false, true, 0); }
-                } else if (m_now == CM) { if (snt) BZ_LAUNCH_SXR(true, true, -1); else BZ_LAUNCH_SXR(false, true, -1); }
-                else { if (snt) BZ_LAUNCH_SXR(true, false, -1); else BZ_LAUNCH_SXR(false, false, -1); }
+                    const int sdepth = slackdepth_env_;
+                    const bool hk = slack_hk;
+                    form_[C_FUSED_IT] += hk ? "(fast,l1-box)" : "(fast)";
+                    if (hk && sdepth >= 1) { if (snt) BZ_LAUNCH_SXR_U(true, 1, 1); else BZ_LAUNCH_SXR_U(false, 1, 1); }
+                    else if (hk) { if (snt) BZ_LAUNCH_SXR_U(true, 1, 0); else BZ_LAUNCH_SXR_U(false, 1, 0); }
+                    else { if (snt) BZ_LAUNCH_SXR_U(true, 0, 0); else BZ_LAUNCH_SXR_U(false, 0, 0); }
+                } else if (m_now == CM) { if (snt) BZ_LAUNCH_SXR(true, true, -1, 0, 0); else BZ_LAUNCH_SXR(false, true, -1, 0, 0); }
+                else { if (snt) BZ_LAUNCH_SXR(true, false, -1, 0, 0); else BZ_LAUNCH_SXR(false, false, -1, 0, 0); }
+#undef BZ_LAUNCH_SXR_U
 #undef BZ_LAUNCH_SXR
                 sy_stale_ = true; rh_stale_ = true; res_skipped = true;
                 trial_ok = false;      // (a tau-backtracked point finishes in the generic chain, after the pairs are re-materialised)

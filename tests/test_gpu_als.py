@@ -243,8 +243,10 @@ def test_slack_iterate_history_form_is_bitwise_neutral(bz, ref, n, iters, start,
     pin = {"BZ_GFC": "2", "BZ_GRID": "512"}
     runs = {}
     for name, env in (("pairs", dict(pin, BZ_XR="0")), ("iterates", dict(pin, BZ_XR="2")), ("iterates-z", dict(pin, BZ_XR="2", BZ_SKIPZ="0")),
-                      ("iterates-nt", dict(pin, BZ_XR="2", BZ_NT="1")), ("iterates-generic", dict(pin, BZ_XR="2", BZ_SLACKFAST="0"))):
-        for k in ("BZ_XR", "BZ_SKIPZ", "BZ_NT", "BZ_GFC", "BZ_GRID", "BZ_SLACKFAST"):
+                      ("iterates-nt", dict(pin, BZ_XR="2", BZ_NT="1")), ("iterates-generic", dict(pin, BZ_XR="2", BZ_SLACKFAST="0")),
+                      # (the fast instantiations with run-time kinds of g and D; with the kinds fixed but no register pipeline)
+                      ("iterates-rtkinds", dict(pin, BZ_XR="2", BZ_SLACKKIND="0")), ("iterates-depth0", dict(pin, BZ_XR="2", BZ_SLACKDEPTH="0"))):
+        for k in ("BZ_XR", "BZ_SKIPZ", "BZ_NT", "BZ_GFC", "BZ_GRID", "BZ_SLACKFAST", "BZ_SLACKKIND", "BZ_SLACKDEPTH"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -261,12 +263,12 @@ def test_slack_iterate_history_form_is_bitwise_neutral(bz, ref, n, iters, start,
         prob.close()
     base = runs["pairs"]
     assert base[5] == 0
-    for name in ("iterates", "iterates-z", "iterates-nt", "iterates-generic"):
+    for name in ("iterates", "iterates-z", "iterates-nt", "iterates-generic", "iterates-rtkinds", "iterates-depth0"):
         r = runs[name]
         assert r[5] >= max(4, iters - 12 - 7 * base[4][2] - 2 * base[4][0] - base[4][1]), (name, r[5], base[4])
         assert r[6].startswith("k_fused_slack_xr<NT=1>" if name == "iterates-nt" else "k_fused_slack_xr<NT=0>"), r[6]
         # (the compile-time instantiations serve f = DiagQuadratic without vector-valued parameters: NormL1Box's u is one)
-        assert r[6].endswith("(fast)") == (g != "l1box" and name != "iterates-generic"), (name, r[6])
+        assert ("(fast" in r[6]) == (g != "l1box" and name != "iterates-generic"), (name, r[6])
         for a, b in zip(r[:3], base[:3]):
             assert np.array_equal(a, b), name
         for key in ("k", "gamma", "tau", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_mem", "lbfgs_H", "FBE"):

@@ -138,9 +138,10 @@ __device__ __forceinline__ double fold_wave(const double* p, int count, bool is_
 
 // block-reduce K accumulators and write one partial per slot.
 // maxmask bit k set -> slot k is a max.
+// (vb: the block's number within its section of the launch, bz_for_chunks_v; default: the launch is one section)
 template <int K>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[K], unsigned maxmask,
-                                                   double* parts, int first_slot) {
+                                                   double* parts, int first_slot, int vb = -1) {
     __shared__ double sh[WAVES][K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[K], unsigned ma
         double t = ((maxmask >> k) & 1u)
                        ? nanmax(nanmax(sh[0][k], sh[1][k]), nanmax(sh[2][k], sh[3][k]))
                        : ((sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]));
-        parts[(size_t)(first_slot + k) * PSTRIDE + blockIdx.x] = t;
+        parts[(size_t)(first_slot + k) * PSTRIDE + (vb >= 0 ? vb : (int)blockIdx.x)] = t;
     }
 }
 
@@ -328,6 +329,18 @@ __device__ __forceinline__ void bz_for_chunks(int64_t n, F&& f) {
     const int64_t nfull = n / N;
     const int64_t st = (int64_t)gridDim.x * BLOCK;
     int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    for (; c < nfull; c += st) f(c * N, std::integral_constant<int, N>{});
+    if (c == nfull && nfull * N < n) f(c * N, (int)(n - nfull * N));
+}
+// the same map for a SECTION of a launch that plays a grid of `vg` blocks of its own, this block being number `vb` of it
+// (k_dense_head / k_dense_tail: several short element-wise kernels as sections of one launch, each with the chunk map —
+// and therefore the partial sums — it has as a launch of its own)
+template <class T, class F>
+__device__ __forceinline__ void bz_for_chunks_v(int64_t n, int vb, int vg, F&& f) {
+    constexpr int N = PackN<T>::N;
+    const int64_t nfull = n / N;
+    const int64_t st = (int64_t)vg * BLOCK;
+    int64_t c = (int64_t)vb * BLOCK + threadIdx.x;
     for (; c < nfull; c += st) f(c * N, std::integral_constant<int, N>{});
     if (c == nfull && nfull * N < n) f(c * N, (int)(n - nfull * N));
 }
@@ -2559,6 +2572,269 @@ k_image_pair(const T* __restrict__ xnew, const T* __restrict__ xold, const T* __
         st(s_img, i0, cnt, s);
         st(y_img, i0, cnt, y);
     });
+}
+
+// ---------------------------------------------------------------------------
+// cfg 4 with affine images (dense c, one pass over A per iteration): the short element-wise kernels either side of
+// k_dense_fused as TWO launches.  Each of them is 3-10 us of which most is launch latency, and the ones in front of the
+// pass over A are issued right after the host's read-back, when the queue is empty: eleven launches cost the iteration
+// ~100 us next to the 360 us pass.  The sections below are those kernels' bodies, operation for operation, on the block ->
+// chunk map each has as a launch of its own (bz_for_chunks_v), with the values that one kernel wrote and the next one read
+// at the same index kept in registers: same bits in every vector and every partial sum (test_gpu_dense.py).
+//   k_dense_head:  blocks [0, gn): k_compact_xd -> k_affine_image (grad L) -> k_fvalue_elem -> k_fbstep   (x-space)
+//                  blocks [gn, gn + gy): k_affine_image (c) -> k_yupd                                       (constraint space)
+//   k_dense_tail:  blocks [0, gn): k_gemv_t_finish -> k_update_c -> k_image_pair (grad L)
+//                  blocks [gn, gn + gy): k_image_pair (c)
+// ---------------------------------------------------------------------------
+template <class T, int MM> struct DenseHeadArgs {
+    CompactVecs<T, MM> V, VG, VA;        // the L-BFGS pairs ; their images under grad L ; under c
+    CompactCoef<MM> C;
+    const T *res, *x;                    // k_compact_xd
+    T* x_d;
+    const T *gbase, *gzimg;              // grad L(x), grad L(z): the image of x_d under grad L goes to gout
+    T* gout;
+    const T *cbase, *czimg;              // c(x), c(z) -> cout ; yupd of it -> yupd
+    T *cout, *yupd;
+    T *z, *res_new;                      // k_fbstep at (x_d, gout)
+    T gamma;
+    int64_t n, ny;
+    double* parts;
+    int slot_f, slot_pen, slot_fb, gn, gy;
+};
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_dense_head(DenseHeadArgs<T, MM> A, ElemParams<T> P) {
+    T u1[MM], u2h[MM];
+    compact_coefs<T, MM>(A.C, u1, u2h);
+    const T H0 = (T)A.C.H0;
+    if ((int)blockIdx.x < A.gn) {
+        const int vb = blockIdx.x;
+        const T gl = A.gamma * P.g_lambda;
+        double accf[1] = {0.0}, acc[3] = {0.0, 0.0, 0.0};
+        bz_for_chunks_v<T>(A.n, vb, A.gn, [&](const int64_t i0, const auto cnt_) {
+            const int cnt = cnt_;
+            // x_d = x + H(-res)   (k_compact_xd)
+            Pack<T> pres = ld(A.res, i0, cnt), px = ld(A.x, i0, cnt), ps[MM], py[MM], d, xd;
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < A.V.m) { ps[i] = ld(A.V.S[i], i0, cnt); py[i] = ld(A.V.Y[i], i0, cnt); }
+            compact_d<T, MM>(A.V.m, H0, u1, u2h, pres, ps, py, d);
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) xd.v[e] = px.v[e] + d.v[e];
+            st(A.x_d, i0, cnt, xd);
+            // grad L(x_d) as the image of x_d   (k_affine_image)
+            Pack<T> pb = ld(A.gbase, i0, cnt), pz = ld(A.gzimg, i0, cnt), g;
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < A.VG.m) { ps[i] = ld(A.VG.S[i], i0, cnt); py[i] = ld(A.VG.Y[i], i0, cnt); }
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                T a = H0 * (pz.v[e] - pb.v[e]);
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < A.VG.m) a = mul_add(u1[i], ps[i].v[e], a);
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < A.VG.m) a = mul_add(u2h[i], py[i].v[e], a);
+                g.v[e] = pb.v[e] + a;
+            }
+            st(A.gout, i0, cnt, g);
+            // f(x_d)   (k_fvalue_elem, element-wise f)
+            if (P.f_kind == BZ_F_DIAG_QUADRATIC) {
+                Pack<T> q = ld(P.q, i0, cnt), b = ld(P.b, i0, cnt);
+#pragma unroll
+                for (int e = 0; e < PackN<T>::N; ++e)
+                    if (e < cnt) {
+                        T qx = q.v[e] * xd.v[e];
+                        accf[0] += (double)(xd.v[e] * (T(0.5) * qx - b.v[e]));
+                    }
+            }
+            // z = prox_{gamma g}(x_d - gamma grad L(x_d)), res = x_d - z   (k_fbstep)
+            ElemLoads<T> L;
+            load_params(P, i0, cnt, L, false, false, true);
+            Pack<T> zp, rp;
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                T t = A.gamma * g.v[e];
+                T y = xd.v[e] - t;
+                T gterm;
+                T zz = prox_elem<T, false>(P.g_kind, y, gl, L.gu.v[e], L.glo.v[e], L.ghi.v[e], gterm, P.g_p);
+                T r = xd.v[e] - zz;
+                zp.v[e] = zz; rp.v[e] = r;
+                if (e < cnt) {
+                    acc[0] += (double)gterm;
+                    acc[1] += (double)(g.v[e] * r);
+                    acc[2] += (double)(r * r);
+                }
+            }
+            st(A.z, i0, cnt, zp);
+            st(A.res_new, i0, cnt, rp);
+        });
+        block_reduce_store<1>(accf, 0u, A.parts, A.slot_f, vb);
+        block_reduce_store<3>(acc, 0u, A.parts, A.slot_fb, vb);
+    } else {
+        const int vb = (int)blockIdx.x - A.gn;
+        double acc[1] = {0.0};
+        bz_for_chunks_v<T>(A.ny, vb, A.gy, [&](const int64_t i0, const auto cnt_) {
+            const int cnt = cnt_;
+            // c(x_d) as the image of x_d   (k_affine_image)
+            Pack<T> pb = ld(A.cbase, i0, cnt), pz = ld(A.czimg, i0, cnt), ps[MM], py[MM], c, yu;
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < A.VA.m) { ps[i] = ld(A.VA.S[i], i0, cnt); py[i] = ld(A.VA.Y[i], i0, cnt); }
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                T a = H0 * (pz.v[e] - pb.v[e]);
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < A.VA.m) a = mul_add(u1[i], ps[i].v[e], a);
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+                    if (i < A.VA.m) a = mul_add(u2h[i], py[i].v[e], a);
+                c.v[e] = pb.v[e] + a;
+            }
+            st(A.cout, i0, cnt, c);
+            // the penalty term and yupd at it   (k_yupd)
+            ElemLoads<T> L;
+            load_params(P, i0, cnt, L, false, true, false);
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                T t = c.v[e] + L.muy.v[e];
+                T sv = proj_D(P.D_kind, t, L.dlo.v[e], L.dhi.v[e]);
+                t = t - sv;
+                T pterm = (t * t) / L.mu.v[e];
+                yu.v[e] = t / L.mu.v[e];
+                if (e < cnt) acc[0] += (double)pterm;
+            }
+            st(A.yupd, i0, cnt, yu);
+        });
+        block_reduce_store<1>(acc, 0u, A.parts, A.slot_pen, vb);
+    }
+}
+
+template <class T, int MM> struct DenseTailArgs {
+    CompactVecs<T, MM> V;                // the stored pairs (k_update_c's Gram products)
+    const T* part;                       // k_gemv_t_finish: row-group partials of A'yhat, nchunks of pstride
+    int nchunks;
+    int64_t pstride;
+    const T *z;                          // the point of this gradient (f terms)
+    T* gz;                               // grad L(z) out
+    const T *x, *x_prev, *res, *res_prev, *gx;      // k_update_c
+    T gamma;
+    T *s_new, *y_new;
+    const T *gx_prev, *gz_prev;          // k_image_pair (grad L): s_img = gx - gx_prev ; y_img = (gx - gz) - (gx_prev - gz_prev)
+    T *gs_img, *gy_img;
+    const T *cx, *cx_prev, *cz, *cz_prev;           // k_image_pair (c)
+    T *cs_img, *cy_img;
+    int64_t n, ny;
+    double* parts;
+    int slot_fz, slot_upd, gn, gy;
+};
+template <class T, int MM>
+__global__ void __launch_bounds__(BLOCK)
+k_dense_tail(DenseTailArgs<T, MM> A, ElemParams<T> P) {
+    if ((int)blockIdx.x < A.gn) {
+        const int vb = blockIdx.x;
+        constexpr int NS = 5 + 4 * MM + 2;
+        double accf[1] = {0.0}, acc[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+        const int m = A.V.m;
+        bz_for_chunks_v<T>(A.n, vb, A.gn, [&](const int64_t i0, const auto cnt_) {
+            const int cnt = cnt_;
+            // grad L(z) = df(z) + the row-group partials in their fixed order   (k_gemv_t_finish)
+            Pack<T> j = ld(A.part, i0, cnt);
+            int k = 1;
+            for (; k + 7 < A.nchunks; k += 8) {
+                Pack<T> q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = ld(A.part + (int64_t)(k + u) * A.pstride, i0, cnt);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < PackN<T>::N; ++e) j.v[e] = j.v[e] + q[u].v[e];
+            }
+            for (; k < A.nchunks; ++k) {
+                Pack<T> q = ld(A.part + (int64_t)k * A.pstride, i0, cnt);
+#pragma unroll
+                for (int e = 0; e < PackN<T>::N; ++e) j.v[e] = j.v[e] + q.v[e];
+            }
+            Pack<T> pzz = ld(A.z, i0, cnt), pq = splat(T(0)), pbb = splat(T(0)), pgz;
+            if (P.f_kind == BZ_F_DIAG_QUADRATIC) { pq = ld(P.q, i0, cnt); pbb = ld(P.b, i0, cnt); }
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                T dfx = T(0), fterm = T(0);
+                if (P.f_kind == BZ_F_DIAG_QUADRATIC) {
+                    T qx = pq.v[e] * pzz.v[e];
+                    dfx = qx - pbb.v[e];
+                    fterm = pzz.v[e] * (T(0.5) * qx - pbb.v[e]);
+                }
+                pgz.v[e] = dfx + j.v[e];
+                if (e < cnt) accf[0] += (double)fterm;
+            }
+            st(A.gz, i0, cnt, pgz);
+            // the pair, the stop norm and the compact form's products   (k_update_c)
+            Pack<T> px = ld(A.x, i0, cnt), pxp = ld(A.x_prev, i0, cnt), pr = ld(A.res, i0, cnt), prp = ld(A.res_prev, i0, cnt);
+            Pack<T> pgx = ld(A.gx, i0, cnt), ps, py, hs[MM], hy[MM];
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < m) { hs[i] = ld(A.V.S[i], i0, cnt); hy[i] = ld(A.V.Y[i], i0, cnt); }
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                T sv = px.v[e] - pxp.v[e];
+                T yv = pr.v[e] - prp.v[e];
+                ps.v[e] = sv; py.v[e] = yv;
+                T w = pr.v[e] / A.gamma;
+                w = w - pgx.v[e];
+                w = w + pgz.v[e];
+                if (e < cnt) {
+                    acc[0] += (double)(sv * yv);
+                    acc[1] += (double)(yv * yv);
+                    acc[2] = nanmax(acc[2], (double)(w < T(0) ? -w : w));
+                    const T nr = T(-1) * pr.v[e];
+#pragma unroll
+                    for (int i = 0; i < MM; ++i)
+                        if (i < m) {
+                            acc[3 + i] = mul_acc(hs[i].v[e], yv, acc[3 + i]);
+                            acc[3 + MM + i] = mul_acc(hy[i].v[e], yv, acc[3 + MM + i]);
+                            acc[3 + 2 * MM + i] = mul_acc(hs[i].v[e], nr, acc[3 + 2 * MM + i]);
+                            acc[3 + 3 * MM + i] = mul_acc(hy[i].v[e], nr, acc[3 + 3 * MM + i]);
+                        }
+                    acc[3 + 4 * MM] = mul_acc(sv, nr, acc[3 + 4 * MM]);
+                    acc[3 + 4 * MM + 1] = mul_acc(yv, nr, acc[3 + 4 * MM + 1]);
+                }
+            }
+            st(A.s_new, i0, cnt, ps);
+            st(A.y_new, i0, cnt, py);
+            // the images of the candidate pair under grad L   (k_image_pair)
+            Pack<T> b = ld(A.gx_prev, i0, cnt), dd = ld(A.gz_prev, i0, cnt), si, yi;
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                si.v[e] = pgx.v[e] - b.v[e];
+                const T rn = pgx.v[e] - pgz.v[e], ro = b.v[e] - dd.v[e];
+                yi.v[e] = rn - ro;
+            }
+            st(A.gs_img, i0, cnt, si);
+            st(A.gy_img, i0, cnt, yi);
+        });
+        block_reduce_store<1>(accf, 0u, A.parts, A.slot_fz, vb);
+        block_reduce_store<NS>(acc, 4u, A.parts, A.slot_upd, vb);
+    } else {
+        const int vb = (int)blockIdx.x - A.gn;
+        // the images of the candidate pair under c   (k_image_pair)
+        bz_for_chunks_v<T>(A.ny, vb, A.gy, [&](const int64_t i0, const auto cnt_) {
+            const int cnt = cnt_;
+            Pack<T> a = ld(A.cx, i0, cnt), b = ld(A.cx_prev, i0, cnt), c = ld(A.cz, i0, cnt), d = ld(A.cz_prev, i0, cnt), s, y;
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) {
+                s.v[e] = a.v[e] - b.v[e];
+                const T rn = a.v[e] - c.v[e], ro = b.v[e] - d.v[e];
+                y.v[e] = rn - ro;
+            }
+            st(A.cs_img, i0, cnt, s);
+            st(A.cy_img, i0, cnt, y);
+        });
+    }
 }
 
 // history as iterates -> history as pairs: S[i] = XH[i+1] - XH[i], Y[i] = RH[i+1] - RH[i] for the MM stored pairs

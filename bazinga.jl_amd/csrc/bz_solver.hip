@@ -822,6 +822,7 @@ template <class T> class Solver final : public SolverBase {
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
     int slackfast_env_ = 1;      // BZ_SLACKFAST=0: the slack iterate-history pass always in its run-time-kinds instantiation
+    int densesmall_env_ = 1;     // BZ_DENSESMALL=0: cfg 4's short kernels either side of the pass over A as launches of their own (k_dense_head / k_dense_tail off)
     int slackkind_env_ = 1;      // BZ_SLACKKIND=0: its fast instantiations with run-time kinds of g and D
     int slackdepth_env_ = 1;     // BZ_SLACKDEPTH=0: ... without the one-pack-ahead register pipeline (232 against 227 us per pass)
     int nt_env_ = -1;            // BZ_NT: -1 (default) non-temporal streams by working-set size, 0 / 1 forced
@@ -2244,6 +2245,7 @@ template <class T> class Solver final : public SolverBase {
         nt_env_ = std::getenv("BZ_NT") ? std::atoi(std::getenv("BZ_NT")) : -1;
         slackfast_env_ = std::getenv("BZ_SLACKFAST") ? std::atoi(std::getenv("BZ_SLACKFAST")) : 1;
         slackkind_env_ = std::getenv("BZ_SLACKKIND") ? std::atoi(std::getenv("BZ_SLACKKIND")) : 1;
+        densesmall_env_ = std::getenv("BZ_DENSESMALL") ? std::atoi(std::getenv("BZ_DENSESMALL")) : 1;
         slackdepth_env_ = std::getenv("BZ_SLACKDEPTH") ? std::atoi(std::getenv("BZ_SLACKDEPTH")) : 1;
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
@@ -2499,6 +2501,7 @@ template <class T> class Solver final : public SolverBase {
         // a backtracked trial point can go through the one-pass kernel too ("trial given" variant) when this
         // iteration's first trial did: what that launch used is kept here
         bool trial_ok = false, trial_nt = false;
+        bool head_on = false, head_fb = false;      // cfg 4: k_dense_head serves this iteration ; ... and has made the FB step of its first trial
         int trial_uni = 0, trial_gfc = 0, trial_fam = -1;
         bool trial_table = false;
         CompactVecs<T, CM> trial_XV;
@@ -2718,8 +2721,14 @@ template <class T> class Solver final : public SolverBase {
             n_grad += 2; n_prox += 1;
         } else {
             if (!res_valid) ensure_z();
+            // cfg 4 with images: x_d, its images under grad L and c, L(x_d) and the forward-backward step in ONE launch
+            // (k_dense_head; single rank, element-wise f, the common prox kinds)
+            head_on = densesmall_env_ && use_compact && aff_track_ && !stencil_fast_now && !generic_ && !ctx->multi() && !lp_g &&
+                      !dense_f && gx_valid && gz_valid && aff_count_ + 1 < aff_refresh_ &&
+                      (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC);
             // x_d = x + d ; gradient at x_d ; state.x = x_d
-            if (use_compact) {
+            if (head_on) {
+            } else if (use_compact) {
                 mv(2 * CV.m + 3);
                 // (full memory + a history beyond the Infinity Cache: compile-time trip counts, non-temporal history loads)
                 static const int xdnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
@@ -2796,6 +2805,25 @@ template <class T> class Solver final : public SolverBase {
                 if (use_compact && gx_valid && gz_valid && aff_count_ + 1 < aff_refresh_) {
                     ++aff_count_; ++n_affine_; img_trial = true;
                     CompactVecs<T, CM> VA = image_vecs(true), VG = image_vecs(false);
+                    if (head_on) {
+                        DenseHeadArgs<T, CM> a;
+                        std::memset(&a, 0, sizeof(a));
+                        a.V = CV; a.VG = VG; a.VA = VA; a.C = CC;
+                        a.res = RES_[rp].p; a.x = X_[xp].p; a.x_d = X_[xd].p;
+                        a.gbase = GX_.p; a.gzimg = GZ_.p; a.gout = GXN_.p;
+                        a.cbase = CXS_.p; a.czimg = CZS_.p; a.cout = CXD_.p; a.yupd = YU_.p;
+                        a.z = Z_[zn].p; a.res_new = RES_[rn].p; a.gamma = gamma;
+                        a.n = n; a.ny = ny; a.parts = parts_.p;
+                        a.slot_f = SL_FXD; a.slot_pen = SL_PXD; a.slot_fb = SL_GSUM; a.gn = grid; a.gy = grid_y;
+                        slot_n[SL_FXD] = grid; slot_n[SL_PXD] = grid_y;
+                        for (int kk = 0; kk < 3; ++kk) slot_n[SL_GSUM + kk] = grid;
+                        // (what the six kernels move: k_compact_xd, the two images, f, yupd, the FB step)
+                        mv(2 * CV.m + 3); mv(2 * VA.m + 3, ny); mv(2 * VG.m + 3); mv(1 + pstreams(true, false, false));
+                        mv(2 + pstreams(false, true, false), ny); mv(4 + pstreams(false, false, true));
+                        nm("k_dense_head");
+                        launch(C_MISC, k_dense_head<T, CM>, grid + grid_y, a, P);
+                        head_fb = true;
+                    } else {
                     mv(2 * VA.m + 3, ny); nm("k_affine_image");
                     launch(C_MISC, k_affine_image<T, CM>, grid_y, VA, CC, (const T*)CXS_.p, (const T*)CZS_.p, CXD_.p, ny);
                     mv(2 * VG.m + 3);
@@ -2806,6 +2834,7 @@ template <class T> class Solver final : public SolverBase {
                     launch(C_MISC, k_fvalue_elem<T>, grid, (const T*)X_[xd].p, P, n, parts_.p, (int)SL_FXD, (const T*)nullptr);
                     mv(2 + pstreams(false, true, false), ny);
                     launch(C_MISC, k_yupd<T>, grid_y, (const T*)CXD_.p, P, YU_.p, ny, parts_.p, (int)SL_PXD);
+                    }
                 } else {
                     aff_count_ = 0;
                     cx_keep_ = CXD_.p;
@@ -2828,11 +2857,41 @@ template <class T> class Solver final : public SolverBase {
         for (int k = 1; k <= max_bt; ++k) {
             if (!have_trial) {
                 if (!gx_valid) { algrad(X_[xcur].p, GX_.p, SL_FXD); gx_valid = true; }
-                fbstep(X_[xcur].p, GX_.p, gamma, Z_[zn].p, RES_[rn].p, SL_GSUM);
+                if (head_fb) head_fb = false;      // (k_dense_head made this step already)
+                else fbstep(X_[xcur].p, GX_.p, gamma, Z_[zn].p, RES_[rn].p, SL_GSUM);
                 gather(SL_GSUM, 3, 0u);
                 ++n_prox;
                 T* const gz_dst = aff_track_ ? GZN_.p : GZ_.p;      // (affine images: grad L(z_prev) is still needed)
                 if (aff_track_) cx_keep_ = CZN_.p;
+                // cfg 4: the fold of the row-group partials, the pair with its products and the pair's images in ONE launch
+                // behind the pass over A (k_dense_tail)
+                const bool tail_on = densesmall_env_ && aff_track_ && compact_ok && !generic_ && !ctx->multi() &&
+                                     desc.c_kind == BZ_C_DENSE_AFFINE && dense_fused_on();
+                if (tail_on) {
+                    slot_n[SL_FZ] = grid;
+                    dense_fused_launch(Z_[zn].p, SL_FZ + 1);
+                    ++n_grad; gz_valid = true;
+                    cx_keep_ = nullptr;
+                    const CompactVecs<T, CM> VG = compact_vecs();
+                    DenseTailArgs<T, CM> a;
+                    std::memset(&a, 0, sizeof(a));
+                    a.V = VG; a.part = GT_.p; a.nchunks = df_groups_; a.pstride = npad;
+                    a.z = Z_[zn].p; a.gz = gz_dst;
+                    a.x = X_[xcur].p; a.x_prev = X_[xp].p; a.res = RES_[rn].p; a.res_prev = RES_[rp].p; a.gx = GX_.p;
+                    a.gamma = gamma; a.s_new = S_[spare].p; a.y_new = Y_[spare].p;
+                    a.gx_prev = GXN_.p; a.gz_prev = GZ_.p; a.gs_img = GS_[spare].p; a.gy_img = GY_[spare].p;
+                    a.cx = CXD_.p; a.cx_prev = CXS_.p; a.cz = CZN_.p; a.cz_prev = CZS_.p;
+                    a.cs_img = AS_[spare].p; a.cy_img = AY_[spare].p;
+                    a.n = n; a.ny = ny; a.parts = parts_.p; a.slot_fz = SL_FZ; a.slot_upd = SL_YS; a.gn = grid; a.gy = grid_y;
+                    for (int kk = 0; kk < 3 + 4 * CM + 2; ++kk) slot_n[SL_YS + kk] = grid;
+                    // (what the four kernels move: the fold + f terms, k_update_c, the two image pairs)
+                    mv(df_groups_ + 2 + pstreams(true, false, false)); mv(8 + 2 * VG.m); mv(6, ny); mv(6);
+                    nm("k_dense_tail");
+                    launch(C_UPDATE, k_dense_tail<T, CM>, grid + grid_y, a, P);
+                    gather(SL_FZ, 2, 0u, 2u);
+                    gather(SL_YS, 3 + 4 * CM + 2, 4u);
+                    gen_gram = true; m_gram = VG.m; tail_used = false;
+                } else {
                 algrad(Z_[zn].p, gz_dst, SL_FZ); ++n_grad; gz_valid = true;
                 cx_keep_ = nullptr;
                 if (compact_ok) {
@@ -2862,6 +2921,7 @@ template <class T> class Solver final : public SolverBase {
                     mv(6);
                     launch(C_MISC, k_image_pair<T>, grid, (const T*)GX_.p, (const T*)GXN_.p, (const T*)GZN_.p,
                            (const T*)GZ_.p, GS_[spare].p, GY_[spare].p, n);
+                }
                 }
             }
             if ((have_trial && gram_from_trial) || gen_gram) {

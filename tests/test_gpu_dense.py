@@ -80,6 +80,50 @@ def test_affine_images_halve_the_passes_over_A(bz, ref, fused, monkeypatch):
     assert (counts[0][3] > 0) == (fused == "1") and counts[0][4].startswith("k_dense_fused" if fused == "1" else "k_gemv_n")
 
 
+@pytest.mark.parametrize("f", ["zero", "diag"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(512, 4096), (260, 1028)])
+def test_short_kernels_as_two_launches_are_bitwise_neutral(bz, ref, shape, dtype, f, monkeypatch):
+    """cfg 4's eleven short element-wise kernels either side of the pass over A run as TWO launches (k_dense_head: x_d, its
+    images under grad L and c, L(x_d), the forward-backward step; k_dense_tail: the fold of the row-group partials, the pair
+    with its products, the pair's images): the kernels' own bodies on the kernels' own block -> chunk maps, so every vector
+    and every scalar of every iteration keeps its bits — across refreshes, backtracks and step-size halvings — and the
+    iteration is five launches (head, pass over A, tail, read-back; the hand-over of the pair) instead of twelve."""
+    ny, n = shape
+    d, dev, orc = make_cfg4(bz, ref, ny, n, dtype, density=0.05)
+    if f == "diag":
+        rng = np.random.default_rng(9)
+        dev = (bz.DiagQuadratic(rng.uniform(0.5, 2.0, n).astype(dtype), rng.standard_normal(n).astype(dtype)),) + tuple(dev[1:])
+    mu, y = np.full(ny, 0.1, dtype), (0.1 * np.random.default_rng(2).standard_normal(ny)).astype(dtype)
+    x0 = np.zeros(n, dtype)
+    runs = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("BZ_DENSESMALL", small)
+        prob = bz.Problem(*dev, n, ny, dtype)
+        prob.set_multipliers(mu, y)
+        prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, minimum_gamma=float(np.finfo(dtype).eps), affine_refresh=8).c_opts(), x0)
+        trace = []
+        for k in range(40):
+            if k == 20:
+                prob.profile_reset(); prob.profile_enable(True)
+            prob.panoc_step()
+            if k % 4 == 3 or k < 4:
+                trace.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars()))
+        p = prob.profile2()
+        st = prob.panoc_stats()
+        runs[small] = (trace, sum(v["launches"] for v in p.values()), st.n_affine_images, st.n_backtracks, st.n_gamma_halvings,
+                       st.n_dense_onepass)
+        prob.close()
+    a, b = runs["1"], runs["0"]
+    assert a[2:] == b[2:] and a[2] >= 25, (a[2:], b[2:])
+    for (xa, za, ra, sa), (xb, zb, rb, sb) in zip(a[0], b[0]):
+        assert np.array_equal(xa, xb) and np.array_equal(za, zb) and np.array_equal(ra, rb)
+        for key in ("k", "gamma", "tau", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_mem", "lbfgs_H", "FBE"):
+            assert sa[key] == sb[key] or (sa[key] != sa[key] and sb[key] != sb[key]), key
+    # 20 profiled iterations: a plain one is 5 launches against 12 (refresh iterations and rejected trials keep their chains)
+    assert a[1] <= b[1] - 6 * 12, (a[1], b[1])
+
+
 def test_affine_images_with_diag_quadratic_f_and_free_set(bz, ref):
     """the other members of the affine class: f = DiagQuadratic (its gradient is affine too), D = FreeSet"""
     ny, n = 48, 300

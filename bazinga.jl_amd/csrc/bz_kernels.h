@@ -1475,14 +1475,18 @@ k_dense_fused(DenseFusedArgs<T> a, ElemParams<T> P) {
     V ring[FNB][FT][KP];
     auto load_tile = [&](auto BI, const int q) { dense_load_tile<T, KP, decltype(BI)::value>(ring, off, a.A, a.n, r0, r1, q); };
     // one slice's FT tagged pairs of tile sequence `seq` -> sh_p[par][sl][.]
-    auto poll_slice = [&](const int par, const int sl, const unsigned long long seq) {
+    // (early: the first poll was issued at the top of the step and `v` is its destination: only its wait is left — the L2
+    // round trip of a poll, ~0.5 us, runs behind the wait for the tile and its products instead of in front of the barrier)
+    auto poll_slice = [&](const int par, const int sl, const unsigned long long seq, bz_u8v& v, const bool early) {
         const unsigned tag32 = ll_tag(seq);
         const unsigned long long tag = (unsigned long long)tag32 << 32;
         const unsigned long long* src = mbox + ((size_t)(seq % FMS) * FG_MAX + sl) * (FT * 2);
         unsigned spins = 0;
+        bool first = early;
         for (;;) {
-            bz_u8v v;
-            asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(src) : "memory");
+            if (first) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+            else asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(src) : "memory");
+            first = false;
             bool ok = true;
 #pragma unroll
             for (int r = 0; r < FT; ++r) ok = ok && v[4 * r + 1] == tag32 && v[4 * r + 3] == tag32;
@@ -1519,6 +1523,20 @@ k_dense_fused(DenseFusedArgs<T> a, ElemParams<T> P) {
     auto step = [&](auto BI, const int p) -> bool {
         constexpr int bi = decltype(BI)::value, bprev = (bi + FNB - 1) % FNB;
         const int par = p & 1;
+        // the polls of tile p - 1's partials go out first: posted a step ago, they are there, and the round trip to L2 runs
+        // behind the wait for tile p and its products (nothing between here and the poll's wait touches pv0 / pv1, and every
+        // path from here reaches that wait — no wave ends with a scalar load in flight: tools/check_dense_ring.py).
+        // Tried beyond this: consuming the partials two steps late — with two tiles in flight instead of three 389 us, with
+        // a fifth ring slot (253 VGPRs) 353 us, the same as this form; and issuing the polls a whole step ahead, right
+        // behind the barrier: slower (374 us).
+        bz_u8v pv0, pv1;
+        const bool early = p > 0 && a.sabotage != 2;
+        const unsigned long long seqp = a.seq0 + (unsigned long long)(p - 1);
+        if (early) {
+            const unsigned long long* src = mbox + ((size_t)(seqp % FMS) * FG_MAX + wave_u) * (FT * 2);
+            if (wave_u < a.G) asm volatile("s_load_dwordx8 %0, %1, 0x0 glc" : "=&s"(pv0) : "s"(src) : "memory");
+            if (wave_u + FWAVES < a.G) asm volatile("s_load_dwordx8 %0, %1, 0x0 glc" : "=&s"(pv1) : "s"(src + (size_t)FWAVES * (FT * 2)) : "memory");
+        }
         dense_wait_tile<T, KP, bi>(ring);
 #pragma unroll
         for (int r = 0; r < FT; ++r) {
@@ -1537,9 +1555,8 @@ k_dense_fused(DenseFusedArgs<T> a, ElemParams<T> P) {
             if (a.sabotage == 2) {                                    // (timing experiment: no exchange, wrong values)
                 if (t < FT) for (int g = 0; g < a.G; ++g) sh_p[par][g][t] = 1.0;
             } else {
-                const unsigned long long seq = a.seq0 + (unsigned long long)(p - 1);
-                if (wave_u < a.G) poll_slice(par, wave_u, seq);
-                if (wave_u + FWAVES < a.G) poll_slice(par, wave_u + FWAVES, seq);
+                if (wave_u < a.G) poll_slice(par, wave_u, seqp, pv0, early);
+                if (wave_u + FWAVES < a.G) poll_slice(par, wave_u + FWAVES, seqp, pv1, early);
             }
         }
         __syncthreads();

@@ -1,6 +1,6 @@
 """Static check of k_dense_fused's register ring (bz_kernels.h): its tile loads are inline asm, invisible to the compiler's
 own wait bookkeeping, so nothing else may touch a load's destination registers between the load and the `s_waitcnt vmcnt(N)`
-statement that retires it.  What CAN be checked on the generated code without a control-flow analysis, and is what went wrong
+statement that retires it; the same holds for the early mailbox polls (scalar loads retired by an asm `s_waitcnt lgkmcnt(0)`).  What CAN be checked on the generated code without a control-flow analysis, and is what went wrong
 once during development (launch bounds that capped the registers at 64 made the compiler spill ring registers right behind
 their loads): no spill code at all in any instantiation, and every ring wait is vmcnt(4 KP) — two tiles left in flight.
 That no live value is copied or re-used in between is covered by the parity tests (tests/test_gpu_dense.py: a register read
@@ -27,6 +27,28 @@ def check_function(name, lines, kp):
     for (ln, _), s in zip(lines, text):
         if s.startswith("scratch_") or re.match(r"buffer_(store|load)_dword.*offen", s):
             findings.append(f"{name}: line {ln}: spill code `{s}`")
+    # the early polls (scalar loads issued at the top of a step, retired by an asm wait after the tile's products): between
+    # such a load and the next `s_waitcnt lgkmcnt(0)` in program order nothing may name its destination registers
+    code = [(ln, s) for (ln, _), s in zip(lines, text) if s and not s.endswith(":") and not s.startswith((".", ";"))]
+    nearly = 0
+    for i, (ln, s) in enumerate(code):
+        m = re.match(r"s_load_dwordx8 s\[(\d+):(\d+)\], .* glc$", s)
+        if not m or (i + 1 < len(code) and code[i + 1][1].startswith("s_waitcnt lgkmcnt(0)")):
+            continue
+        nearly += 1
+        lo, hi = int(m.group(1)), int(m.group(2))
+        for ln2, s2 in code[i + 1:]:
+            if s2.startswith("s_waitcnt lgkmcnt(0)"):
+                break
+            regs = set()
+            for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", s2):
+                regs.update(range(int(a), int(b) + 1))
+            regs.update(int(a) for a in re.findall(r"\bs(\d+)\b", s2))
+            if any(lo <= r <= hi for r in regs) and not re.match(r"s_load_dwordx8 s\[\d+:\d+\], .* glc$", s2):
+                findings.append(f"{name}: line {ln2}: `{s2}` touches s[{lo}:{hi}] of the early poll issued at line {ln}")
+                break
+    if nearly == 0:
+        findings.append(f"{name}: no early poll found (expected one or two per step)")
     waits = [int(m.group(1)) for s in text for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)$", s)] if m]
     ring_waits = [w for w in waits if w not in (0, 1)]
     if not ring_waits or any(w != 4 * kp for w in ring_waits):

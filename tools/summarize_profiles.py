@@ -69,7 +69,7 @@ def form_of(kernel):
     m = re.match(r"k_dense_fused<\w+, (\d+)>$", k)
     if m:
         return f"k_dense_fused<KP={m.group(1)}>"
-    m = re.match(r"k_fused_slack_xr<\w+, \d+, (true|false), (true|false), (-?\d+), (\d+), (\d+)>$", k)
+    m = re.match(r"k_fused_slack_xr<\w+, \d+, (true|false), (true|false), (-?\d+)(?:, (\d+), (\d+))?>$", k)
     if m:      # (the fast instantiations — compile-time UNI >= 0 — carry a "(fast)" suffix, "(fast,l1-box)" with the kinds fixed too: bz_solver.hip)
         return f"k_fused_slack_xr<NT={int(m.group(1) == 'true')}>" + (("(fast,l1-box)" if m.group(4) == "1" else "(fast)") if int(m.group(3)) >= 0 else "")
     m = re.match(r"k_fused_slack<\w+, \d+, (true|false)>$", k)

@@ -465,6 +465,10 @@ def event_period(steps, short_pass=False):
     if os.environ.get("BZ_BENCH_PERIOD"):
         return int(os.environ["BZ_BENCH_PERIOD"])
     p = int(max(4, min(32, steps // 12)))
+    if steps < 48:
+        # a short block (the driver's K = 20): two evented launches per block — five of them were 2 % of the block's time; the
+        # roofline average then also takes the samples of the repeat blocks (same workload, same K: `roofline.sampled_blocks`)
+        p = int(max(4, steps // 2))
     # a short pass (an N = 8 shard: ~20 us) feels the ~14 us an evented, un-gated launch costs twice as much: half as often
     return min(32, 2 * p) if short_pass else p
 
@@ -978,12 +982,14 @@ def main():
     if R["elapsed"] < 0.1:
         nblk = int(min(15, max(4, np.ceil(0.5 / max(R["elapsed"], 1e-6)))))
         ts = [R["elapsed"]]
+        R["prof2_blocks"] = [R["prof2"]]
         for _ in range(nblk):
             prob.panoc_begin(popts, np.zeros(nl))
             rb = timed_run(prob, args.steps, args.warmup)
             if "failed" in rb:
                 break
             ts.append(rb["elapsed"])
+            R["prof2_blocks"].append(rb["prof2"])
         msb = sorted(1e3 * t / args.steps for t in ts)
         repeats = {"blocks": len(ts), "ms_per_step_median": round(msb[len(msb) // 2], 5), "ms_per_step_min": round(msb[0], 5),
                    "ms_per_step_max": round(msb[-1], 5), "value_median": round(1e3 / msb[len(msb) // 2], 3),
@@ -1049,7 +1055,16 @@ def main():
         # unless they travel as numbers) in, x_d out = 9..11 passes; 18..20 with stored pairs; the two-loop path:
         # k_twoloop_persist 4m passes + k_fused_sep 13)
         prof2 = R["prof2"]
+        blocks = R.get("prof2_blocks") or [prof2]
+        if len(blocks) > 1:
+            # event samples of every K-step block (block 1's launch counts and bytes: `value` and the iteration figures stay block 1's)
+            prof2 = {k: dict(v) for k, v in prof2.items()}
+            for k in prof2:
+                for key in ("timed_ms", "timed_launches", "timed_bytes"):
+                    prof2[k][key] = sum(b[k][key] for b in blocks if k in b)
         roof, moved_iter = roofline_of(prof2, ALG, args.workload if headline else args.workload + ":" + args.family, nl, args.steps)
+        if roof:
+            roof["sampled_blocks"] = len(blocks)
         roofline_note(roof, 1e3 * elapsed / args.steps)
         # the reference's dataflow: 65 passes per iteration on this workload at m = 5 — a model of
         # what the reference moves, reported as a ratio, never as a roofline fraction

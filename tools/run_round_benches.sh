@@ -10,10 +10,13 @@ if [ "$2" = "prof" ]; then
   bash tools/collect_profiles.sh cfg3 --workload cfg3
   bash tools/collect_profiles.sh cfg4 --workload cfg4
   bash tools/collect_profiles.sh fam_l1box --family diag-l1box-box
+  bash tools/collect_profiles.sh fam_xor --family diag-l1-xor
   bash tools/collect_profiles.sh als --workload als
   exit 0
 fi
 python bench.py > $o/bench_cfg2.json 2> $o/bench_cfg2.err; echo "cfg2 rc=$?"
+# (the window the round driver runs)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_cfg2_driver_window.json 2> /dev/null; echo "cfg2 driver window rc=$?"
 python bench.py --workload cfg3 > $o/bench_cfg3.json 2> $o/bench_cfg3.err; echo "cfg3 rc=$?"
 python bench.py --workload cfg3 --two-loop --no-cpu-baseline > $o/bench_cfg3_two_loop.json 2> /dev/null; echo "cfg3 two-loop rc=$?"
 python bench.py --workload cfg4 > $o/bench_cfg4.json 2> $o/bench_cfg4.err; echo "cfg4 rc=$?"

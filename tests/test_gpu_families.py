@@ -198,9 +198,12 @@ def test_family_kernels_float32(bz, ref, fam, nt):
     if nt == "nt":
         pin["BZ_NT"] = "1"
     base = _run(bz, dev, n, mu, y, x0, 40, dict(pin, BZ_XR="0"), dtype=np.float32)
-    r = _run(bz, dev, n, mu, y, x0, 40, dict(pin, BZ_XR="2"), dtype=np.float32)
-    assert base[5] == 0 and r[5] >= 5 and "FAM=" in r[6] and ("NT=1" in r[6]) == (nt == "nt")
-    for a, b in zip(r[:3], base[:3]):
-        assert np.array_equal(a, b)
-    for key in SCALARS:
-        assert r[3][key] == base[3][key], key
+    # the compile-time UNI / TRIAL instantiation (fp32 has them since r03), the run-time one, penalties streamed
+    for env in (dict(pin, BZ_XR="2"), dict(pin, BZ_XR="2", BZ_FAMRT="1"), dict(pin, BZ_XR="2", BZ_UNI="0")):
+        r = _run(bz, dev, n, mu, y, x0, 40, env, dtype=np.float32)
+        assert base[5] == 0 and r[5] >= 5 and "FAM=" in r[6] and ("NT=1" in r[6]) == (nt == "nt")
+        assert ("UNI=-1" in r[6]) == bool(env.get("BZ_FAMRT")), r[6]
+        for a, b in zip(r[:3], base[:3]):
+            assert np.array_equal(a, b), env
+        for key in SCALARS:
+            assert r[3][key] == base[3][key], (env, key)

@@ -901,7 +901,7 @@ k_stencil_fb(const T* __restrict__ x, ElemParams<T> P, int64_t nx, int64_t ny, T
                 accG[2] += (double)(r * r);
             }
         }
-        st(grad, i0, cnt, pg);
+        if (grad) st(grad, i0, cnt, pg);      // (null: the pass that follows re-forms it, k_stencil_update_c<REGX>)
         st(z, i0, cnt, pz);
         st(res, i0, cnt, pr);
     });
@@ -2998,13 +2998,19 @@ k_update_c(CompactVecs<T, MM> V, const T* __restrict__ x, const T* __restrict__ 
 //   then <s_new, -res>, <y_new, -res>
 // (slots slot0 + 0..4 are k_stencil_fb's).  With it the iteration has ONE reduction phase and no persistent
 // two-loop kernel with its 2m-1 grid barriers: x_d (k_compact_xd), k_stencil_fb, this.
-template <class T, int MM, bool FULL = false, bool NT = false>
+// REGX (r03): grad L(x_d) and res are not read but re-formed here — res = x_d - z from the two packs this pass loads anyway, and
+// grad L(x_d) by the stencil on x_d (its north / south / west / east re-reads are cache hits: the pass streams x_d already) —
+// the operations of k_stencil_fb on the same operands, so the same bits, for two read streams less here and one write stream
+// less there (k_stencil_fb with grad = null): 39 -> 36 passes over n per iteration.  halo_x: x_d's halo rows (sharded grid).
+// (measured on cfg 3: REGX = 2, both re-formed: 126 us against 117 us for this pass — the second stencil costs more than the two
+// streams it saves ; REGX = 1, res only — a subtraction of two packs the pass holds anyway: the default)
+template <class T, int MM, bool FULL = false, bool NT = false, int REGX = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T> P, int64_t nx, int64_t ny,
                    const T* __restrict__ x, const T* __restrict__ x_prev, const T* __restrict__ res,
                    const T* __restrict__ res_prev, const T* __restrict__ gx, T gamma,
                    T* __restrict__ s_new, T* __restrict__ y_new, int64_t n,
-                   double* __restrict__ parts, int slot0, StencilHalo<T> halo) {
+                   double* __restrict__ parts, int slot0, StencilHalo<T> halo, StencilHalo<T> halo_x = StencilHalo<T>()) {
     constexpr int NS = 5 + 4 * MM + 2;
     double accF[2] = {0.0, 0.0}, acc[NS];
 #pragma unroll
@@ -3014,8 +3020,20 @@ k_stencil_update_c(CompactVecs<T, MM> V, const T* __restrict__ zp, ElemParams<T>
         const int cnt = cnt_;
         Pack<T> zc = ld(zp, i0, cnt);
         Pack<T> pgz = stencil_al_pack<T, NT>(zp, P, nx, ny, 0, i0, cnt, zc, accF[0], accF[1], halo);
-        Pack<T> px = ld(x, i0, cnt), pxp = ldp<T, NT>(x_prev, i0, cnt), pr = ld(res, i0, cnt), prp = ldp<T, NT>(res_prev, i0, cnt);
-        Pack<T> pgx = ld(gx, i0, cnt), ps, py, hs[MM], hy[MM];
+        Pack<T> px = ld(x, i0, cnt), pxp = ldp<T, NT>(x_prev, i0, cnt), pr, prp = ldp<T, NT>(res_prev, i0, cnt);
+        Pack<T> pgx, ps, py, hs[MM], hy[MM];
+        if constexpr (REGX >= 1) {
+#pragma unroll
+            for (int e = 0; e < PackN<T>::N; ++e) pr.v[e] = px.v[e] - zc.v[e];
+        } else {
+            pr = ld(res, i0, cnt);
+        }
+        if constexpr (REGX >= 2) {
+            double dump0 = 0.0, dump1 = 0.0;      // (the value terms at x_d were summed by k_stencil_fb)
+            pgx = stencil_al_pack<T, NT>(x, P, nx, ny, 0, i0, cnt, px, dump0, dump1, halo_x);
+        } else {
+            pgx = ld(gx, i0, cnt);
+        }
 #pragma unroll
         for (int i = 0; i < MM; ++i)
             if (i < m) { hs[i] = ldp<T, NT>(V.S[i], i0, cnt); hy[i] = ldp<T, NT>(V.Y[i], i0, cnt); }

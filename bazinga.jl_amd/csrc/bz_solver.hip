@@ -822,6 +822,7 @@ template <class T> class Solver final : public SolverBase {
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
     int slackfast_env_ = 1;      // BZ_SLACKFAST=0: the slack iterate-history pass always in its run-time-kinds instantiation
+    int stencil_regx_env_ = 1;   // BZ_STENCIL_REGX=0|1|2: cfg 3's second pass reads res and grad L(x_d) / re-forms res (default) / re-forms both (slower)
     int densesmall_env_ = 1;     // BZ_DENSESMALL=0: cfg 4's short kernels either side of the pass over A as launches of their own (k_dense_head / k_dense_tail off)
     int slackkind_env_ = 1;      // BZ_SLACKKIND=0: its fast instantiations with run-time kinds of g and D
     int slackdepth_env_ = 1;     // BZ_SLACKDEPTH=0: ... without the one-pack-ahead register pipeline (232 against 227 us per pass)
@@ -2246,6 +2247,7 @@ template <class T> class Solver final : public SolverBase {
         slackfast_env_ = std::getenv("BZ_SLACKFAST") ? std::atoi(std::getenv("BZ_SLACKFAST")) : 1;
         slackkind_env_ = std::getenv("BZ_SLACKKIND") ? std::atoi(std::getenv("BZ_SLACKKIND")) : 1;
         densesmall_env_ = std::getenv("BZ_DENSESMALL") ? std::atoi(std::getenv("BZ_DENSESMALL")) : 1;
+        stencil_regx_env_ = std::getenv("BZ_STENCIL_REGX") ? std::atoi(std::getenv("BZ_STENCIL_REGX")) : 1;
         slackdepth_env_ = std::getenv("BZ_SLACKDEPTH") ? std::atoi(std::getenv("BZ_SLACKDEPTH")) : 1;
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
@@ -2753,37 +2755,48 @@ template <class T> class Solver final : public SolverBase {
                 for (int sidx = SL_FXD; sidx <= SL_STOP; ++sidx) slot_n[sidx] = grid;
                 // (uniform penalties / zero multipliers travel as numbers, P.uni: the two stencil passes stream mu and mu*y
                 // otherwise — 4 of the iteration's 43 passes)
-                mv(2 + pstreams(false, true, true) + 3);        // x_d, b + parameters ; grad, z, res
+                // (r03: with the compact form the second pass re-forms grad L(x_d) and res from x_d and z — k_stencil_update_c<REGX> —
+                // so this pass does not write the gradient and that one reads neither: 39 -> 36 passes over n per iteration)
+                const int regx = use_compact ? std::max(0, std::min(2, stencil_regx_env_)) : 0;
+                mv(2 + pstreams(false, true, true) + (regx >= 2 ? 2 : 3));        // x_d, b + parameters ; (grad,) z, res
                 const StencilHalo<T> halo_x = halo_exchange(X_[xd].p);
                 static const int fbnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
                 nm(fbnt_env && (double)n * sizeof(T) * 12 > 340e6 ? "k_stencil_fb<NT=1>" : "k_stencil_fb<NT=0>");
                 if (fbnt_env && (double)n * sizeof(T) * 12 > 340e6)
                     launch(C_STENCIL_FB, k_stencil_fb<T, true>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
-                           (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
+                           (int64_t)desc.f_grid_ny, gamma, regx >= 2 ? (T*)nullptr : GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                            (int)SL_GSUM, halo_x);
                 else
                 launch(C_STENCIL_FB, k_stencil_fb<T>, grid, (const T*)X_[xd].p, P, (int64_t)desc.f_grid_nx,
-                       (int64_t)desc.f_grid_ny, gamma, GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
+                       (int64_t)desc.f_grid_ny, gamma, regx >= 2 ? (T*)nullptr : GX_.p, Z_[zn].p, RES_[rn].p, n, parts_.p, (int)SL_FXD,
                        (int)SL_GSUM, halo_x);
                 const StencilHalo<T> halo_z = halo_exchange(Z_[zn].p);
                 if (use_compact) {
                     // ... with the Gram products of the new pair and the next application's p, w in the same pass
                     for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
-                    mv(2 + pstreams(false, true, false) + 5 + 2 + 2 * CV.m);
-#define BZ_LAUNCH_SUC(FULL_, NT_)                                                                                 \
-    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
+                    mv(2 + pstreams(false, true, false) + (5 - regx) + 2 + 2 * CV.m);
+#define BZ_LAUNCH_SUC_R(FULL_, NT_, REGX_)                                                                        \
+    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_, REGX_>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
            (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p, (const T*)RES_[rp].p, \
-           (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL, halo_z)
+           (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL, halo_z, halo_x)
+#define BZ_LAUNCH_SUC(FULL_, NT_)                                                                                 \
+    do { if (regx >= 2) BZ_LAUNCH_SUC_R(FULL_, NT_, 2); else if (regx == 1) BZ_LAUNCH_SUC_R(FULL_, NT_, 1);      \
+         else BZ_LAUNCH_SUC_R(FULL_, NT_, 0); } while (0)
                     {
                         static const int xdnt_env = std::getenv("BZ_XDNT") ? std::atoi(std::getenv("BZ_XDNT")) : 1;
                         const bool hist_nt = xdnt_env && (double)n * sizeof(T) * (2 * CV.m + 12) > 340e6;
-                        nm(CV.m == CM ? (hist_nt ? "k_stencil_update_c<FULL=1,NT=1>" : "k_stencil_update_c<FULL=1,NT=0>")
-                                      : "k_stencil_update_c<FULL=0,NT=0>");
+                        if (regx >= 2) nm(CV.m == CM ? (hist_nt ? "k_stencil_update_c<FULL=1,NT=1,REGX=2>" : "k_stencil_update_c<FULL=1,NT=0,REGX=2>")
+                                                     : "k_stencil_update_c<FULL=0,NT=0,REGX=2>");
+                        else if (regx == 1) nm(CV.m == CM ? (hist_nt ? "k_stencil_update_c<FULL=1,NT=1,REGX=1>" : "k_stencil_update_c<FULL=1,NT=0,REGX=1>")
+                                                          : "k_stencil_update_c<FULL=0,NT=0,REGX=1>");
+                        else nm(CV.m == CM ? (hist_nt ? "k_stencil_update_c<FULL=1,NT=1>" : "k_stencil_update_c<FULL=1,NT=0>")
+                                           : "k_stencil_update_c<FULL=0,NT=0>");
                         if (CV.m == CM && hist_nt) BZ_LAUNCH_SUC(true, true);
                         else if (CV.m == CM) BZ_LAUNCH_SUC(true, false);
                         else BZ_LAUNCH_SUC(false, false);
                     }
 #undef BZ_LAUNCH_SUC
+#undef BZ_LAUNCH_SUC_R
                     if (ctx->p2p_on) {
                         // exchange + fold over the ranks + read-back of all 32 slots in one launch
                         tail_ticket = exchange_collect(SL_TRIAL, NFC, 1u << 9);
@@ -2798,7 +2811,7 @@ template <class T> class Solver final : public SolverBase {
                        (const T*)RES_[rp].p, (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, (T*)nullptr, n, parts_.p,
                        (int)SL_FZ, (int)SL_YS, halo_z);
                 }
-                have_trial = true; gx_valid = true; gz_valid = false;
+                have_trial = true; gx_valid = regx < 2; gz_valid = false;
                 n_grad += 2; n_prox += 1;
             } else if (aff_track_) {
                 // gradient (and c) at x_d into the candidate buffers, then trade: GX_ = grad L(x_d), GXN_ = grad L(x_prev)

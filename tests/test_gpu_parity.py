@@ -217,10 +217,11 @@ def test_fused_equals_generic_bitwise(bz, ref, g):
         out.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"),
                     prob.panoc_scalars()))
         prob.close()
-    (x1, z1, r1, s1), (x2, z2, r2, s2) = out
-    assert np.array_equal(x1, x2) and np.array_equal(z1, z2) and np.array_equal(r1, r2)
-    for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "al_z"):
-        assert s1[key] == s2[key], key
+    (x1, z1, r1, s1) = out[0]
+    for (x2, z2, r2, s2) in out[1:]:
+        assert np.array_equal(x1, x2) and np.array_equal(z1, z2) and np.array_equal(r1, r2)
+        for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "al_z"):
+            assert s1[key] == s2[key], key
     assert s1["fused"] == 1.0 and s2["fused"] == 0.0
 
 
@@ -771,14 +772,16 @@ def test_no_acceleration_direction(bz, ref):
 
 
 @pytest.mark.parametrize("compact", [False, True])
-def test_stencil_fast_path_equals_generic_bitwise(bz, ref, compact):
+def test_stencil_fast_path_equals_generic_bitwise(bz, ref, compact, monkeypatch):
     """cfg 3: the two fused stencil passes ({gradL(x_d) + FB step}, {gradL(z) + pair + stop norm [+ the compact
     form's Gram products and next p, w: k_stencil_update_c]}) are the same arithmetic and the same summation order
-    as the generic kernels they replace, in both forms of the L-BFGS operator."""
+    as the generic kernels they replace, in both forms of the L-BFGS operator — with grad L(x_d) and res re-formed in the
+    second pass (r03, the default with the compact form: 36 passes over n instead of 39) and with both read from memory."""
     nx, ny = 96, 128
     d, n, dev, orc = make_cfg3(bz, ref, nx, ny, load=-1.0)
     out = []
-    for fuse in (True, False):
+    for fuse, regx in ((True, "1"), (False, "1"), (True, "0"), (True, "2")):
+        monkeypatch.setenv("BZ_STENCIL_REGX", regx)
         prob = bz.Problem(*dev, n, n, np.float64)
         prob.set_multipliers(np.full(n, 0.1), np.zeros(n))
         prob.panoc_begin(bz.PANOCplus(tol=0.0, maxit=10 ** 9, fuse=fuse, minimum_gamma=2.3e-16,
@@ -787,10 +790,11 @@ def test_stencil_fast_path_equals_generic_bitwise(bz, ref, compact):
             prob.panoc_step()
         out.append((prob.panoc_vector("x"), prob.panoc_vector("z"), prob.panoc_vector("res"), prob.panoc_scalars()))
         prob.close()
-    (x1, z1, r1, s1), (x2, z2, r2, s2) = out
-    assert np.array_equal(x1, x2) and np.array_equal(z1, z2) and np.array_equal(r1, r2)
-    for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "al_z"):
-        assert s1[key] == s2[key], key
+    (x1, z1, r1, s1) = out[0]
+    for (x2, z2, r2, s2) in out[1:]:
+        assert np.array_equal(x1, x2) and np.array_equal(z1, z2) and np.array_equal(r1, r2)
+        for key in ("gamma", "f_x", "g_z", "dot_grad_res", "ss_res", "stop_norm", "last_ys", "lbfgs_H", "al_z"):
+            assert s1[key] == s2[key], key
 
 
 @pytest.mark.parametrize("seed,form", [(s, "two-loop") for s in range(12)] + [(s, "compact") for s in range(12)])

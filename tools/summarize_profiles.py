@@ -63,9 +63,9 @@ def form_of(kernel):
         if xr == "1":
             return f"k_fused_compact<XR=1,NT={int(nt)}>"
         return f"k_fused_compact<XR=0,SPEC={int(spec)},NT={int(nt)}>"
-    m = re.match(r"(k_compact_xd|k_stencil_update_c)<\w+, \d+(?:, (true|false), (true|false))?>$", k)
+    m = re.match(r"(k_compact_xd|k_stencil_update_c)<\w+, \d+(?:, (true|false), (true|false))?(?:, (\d))?>$", k)
     if m:
-        return f"{m.group(1)}<FULL={int(m.group(2) == 'true')},NT={int(m.group(3) == 'true')}>"
+        return f"{m.group(1)}<FULL={int(m.group(2) == 'true')},NT={int(m.group(3) == 'true')}" + (f",REGX={m.group(4)}>" if m.group(4) not in (None, "0") else ">")
     m = re.match(r"k_dense_fused<\w+, (\d+)>$", k)
     if m:
         return f"k_dense_fused<KP={m.group(1)}>"

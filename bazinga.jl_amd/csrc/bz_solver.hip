@@ -823,6 +823,7 @@ template <class T> class Solver final : public SolverBase {
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
     int slackfast_env_ = 1;      // BZ_SLACKFAST=0: the slack iterate-history pass always in its run-time-kinds instantiation
     int stencil_regx_env_ = 1;   // BZ_STENCIL_REGX=0|1|2: cfg 3's second pass reads res and grad L(x_d) / re-forms res (default) / re-forms both (slower)
+    int affblend_env_ = 1;       // BZ_AFFINE_BLEND=0: a tau-backtracked point of cfg 4 is always evaluated with a pass over A (no images)
     int densesmall_env_ = 1;     // BZ_DENSESMALL=0: cfg 4's short kernels either side of the pass over A as launches of their own (k_dense_head / k_dense_tail off)
     int slackkind_env_ = 1;      // BZ_SLACKKIND=0: its fast instantiations with run-time kinds of g and D
     int slackdepth_env_ = 1;     // BZ_SLACKDEPTH=0: ... without the one-pack-ahead register pipeline (232 against 227 us per pass)
@@ -2247,6 +2248,7 @@ template <class T> class Solver final : public SolverBase {
         slackfast_env_ = std::getenv("BZ_SLACKFAST") ? std::atoi(std::getenv("BZ_SLACKFAST")) : 1;
         slackkind_env_ = std::getenv("BZ_SLACKKIND") ? std::atoi(std::getenv("BZ_SLACKKIND")) : 1;
         densesmall_env_ = std::getenv("BZ_DENSESMALL") ? std::atoi(std::getenv("BZ_DENSESMALL")) : 1;
+        affblend_env_ = std::getenv("BZ_AFFINE_BLEND") ? std::atoi(std::getenv("BZ_AFFINE_BLEND")) : 1;
         stencil_regx_env_ = std::getenv("BZ_STENCIL_REGX") ? std::atoi(std::getenv("BZ_STENCIL_REGX")) : 1;
         slackdepth_env_ = std::getenv("BZ_SLACKDEPTH") ? std::atoi(std::getenv("BZ_SLACKDEPTH")) : 1;
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
@@ -2504,6 +2506,7 @@ template <class T> class Solver final : public SolverBase {
         // iteration's first trial did: what that launch used is kept here
         bool trial_ok = false, trial_nt = false;
         bool head_on = false, head_fb = false;      // cfg 4: k_dense_head serves this iteration ; ... and has made the FB step of its first trial
+        bool state_imgs = false, halved_here = false;      // cfg 4: the state's images are valid ; gamma was halved inside this step
         int trial_uni = 0, trial_gfc = 0, trial_fam = -1;
         bool trial_table = false;
         CompactVecs<T, CM> trial_XV;
@@ -2815,6 +2818,7 @@ template <class T> class Solver final : public SolverBase {
                 n_grad += 2; n_prox += 1;
             } else if (aff_track_) {
                 // gradient (and c) at x_d into the candidate buffers, then trade: GX_ = grad L(x_d), GXN_ = grad L(x_prev)
+                state_imgs = gx_valid && gz_valid;      // (the images of this state's x and z are what GX_, GZ_, CXS_, CZS_ hold)
                 if (use_compact && gx_valid && gz_valid && aff_count_ + 1 < aff_refresh_) {
                     ++aff_count_; ++n_affine_; img_trial = true;
                     CompactVecs<T, CM> VA = image_vecs(true), VG = image_vecs(false);
@@ -2988,6 +2992,7 @@ template <class T> class Solver final : public SolverBase {
             if (sy_stale_ && !trial_ok && (halve || !(FBE_new <= threshold || k >= max_bt))) materialize_pairs();
             if ((!z_valid || !res_valid) && (halve || !(FBE_new <= threshold || k >= max_bt))) ensure_z();
             if (halve) {
+                halved_here = true;
                 gamma = gamma * T(0.5); ++n_halv;
                 if (gamma < min_gamma)
                     std::fprintf(stderr, "Warning: stepsize `gamma` became too small (%g)\n", (double)gamma);
@@ -3035,6 +3040,25 @@ template <class T> class Solver final : public SolverBase {
                 }
                 have_trial = true; gram_from_trial = true; gx_valid = false; gz_valid = false;
                 n_grad += 2; n_prox += 1;
+            } else if (affblend_env_ && aff_track_ && state_imgs && gx_valid && nbt == 1 && !halved_here && compact_ok && !generic_ &&
+                       !ctx->multi() && aff_count_ + 1 < aff_refresh_) {
+                // cfg 4, first tau backtrack of an iteration: the blended point is an affine combination of x_d and the state's z,
+                // whose images under c and grad L are at hand — its images are the same combination (k_blend's operations), no
+                // pass over A.  (As for x_d: a failing step-size test on images is re-run on evaluations, img_trial.)  The rejected
+                // trial's z images (CZN_, GZN_) are dead: they take the results and trade places.
+                ++aff_count_; img_trial = true;      // (n_affine_images counts iterations whose trial point x + d went on images)
+                mv(3, ny);
+                launch(C_MISC, k_blend<T>, grid_y, (const T*)CXD_.p, (const T*)CZS_.p, tau, T(1) - tau, CZN_.p, ny);
+                std::swap(CXD_.p, CZN_.p); std::swap(CXD_.n, CZN_.n);
+                mv(3);
+                launch(C_MISC, k_blend<T>, grid, (const T*)GX_.p, (const T*)GZ_.p, tau, T(1) - tau, GZN_.p, n);
+                std::swap(GX_.p, GZN_.p); std::swap(GX_.n, GZN_.n);
+                slot_n[SL_FXD] = grid; slot_n[SL_PXD] = grid_y;
+                mv(1 + pstreams(true, false, false));
+                launch(C_MISC, k_fvalue_elem<T>, grid, (const T*)X_[xb].p, P, n, parts_.p, (int)SL_FXD, (const T*)nullptr);
+                mv(2 + pstreams(false, true, false), ny);
+                launch(C_MISC, k_yupd<T>, grid_y, (const T*)CXD_.p, P, YU_.p, ny, parts_.p, (int)SL_PXD);
+                ++n_grad; gx_valid = true;
             } else {
                 if (aff_track_) { cx_keep_ = CXD_.p; aff_count_ = 0; img_trial = false; }
                 algrad(X_[xb].p, GX_.p, SL_FXD); ++n_grad; gx_valid = true;

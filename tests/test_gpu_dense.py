@@ -50,6 +50,35 @@ def test_dense_iterates_follow_oracle_with_and_without_affine_images(bz, ref, sh
     prob.close()
 
 
+@pytest.mark.parametrize("blend", ["1", "0"])
+def test_backtracked_trial_points_on_images_follow_the_oracle(bz, ref, blend, monkeypatch):
+    """A tau-backtracked trial point is an affine combination of x + d and the state's z, so its images under c and grad L
+    are that combination of images already held: the first backtrack of an iteration costs no pass over A (r03;
+    `BZ_AFFINE_BLEND=0`: evaluated as before).  60 states of a solve that backtracks six times, against the oracle, inside
+    the oracle's own rounding envelope — and the passes over A that the images save."""
+    ny, n = 64, 512
+    monkeypatch.setenv("BZ_AFFINE_BLEND", blend)
+    d, dev, orc = make_cfg4(bz, ref, ny, n, np.float64, density=0.05)
+    mu, y = np.full(ny, 0.1), 0.1 * np.random.default_rng(2).standard_normal(ny)
+    prob, st, rows = run_traces(bz, ref, dev, orc, n, mu, y, np.zeros(n), 60, minimum_gamma=2.3e-16, ny=ny, affine_refresh=16)
+    stats = prob.panoc_stats()
+    assert stats.n_backtracks >= 4
+    for k, ex, ez, g_d, g_r, sn_d, sn_r, fused, sens in rows:
+        assert abs(g_d - g_r) <= 1e-12 * g_r, k
+        assert ex <= max(1e-9, 100 * sens) and ez <= max(1e-9, 100 * sens), (k, ex, ez, sens)
+    _BLEND_GRADS[blend] = (stats.n_grad, stats.n_dense_onepass, stats.n_backtracks)
+    if len(_BLEND_GRADS) == 2:
+        a, b = _BLEND_GRADS["1"], _BLEND_GRADS["0"]
+        assert a[2] == b[2] and a[0] == b[0]              # the same trajectory of decisions ...
+        assert a[1] <= b[1] - 2, (a, b)                   # ... with fewer passes over A (not one per backtrack: the second backtrack
+                                                          # of an iteration, a trial whose step-size test fails and refresh iterations
+                                                          # are evaluated)
+    prob.close()
+
+
+_BLEND_GRADS = {}
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_affine_images_halve_the_passes_over_A(bz, ref, fused, monkeypatch):
     """traffic accounting (bytes the launches are designed to move, in passes over A): an AL gradient is ONE pass with the

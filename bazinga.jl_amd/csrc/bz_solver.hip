@@ -358,7 +358,7 @@ template <class T> class Solver final : public SolverBase {
 
     void finish(void* x_out, bz_panoc_stats* st) override {
         require_active();
-        if (x_out) { ensure_z(); copy_out(x_out, Z_[zc].p, n); }
+        if (x_out) { ensure_z(false); copy_out(x_out, Z_[zc].p, n); }
         if (st) fill_stats(st);
     }
 
@@ -375,7 +375,7 @@ template <class T> class Solver final : public SolverBase {
         require_active();
         switch (which) {
         case 0: copy_out(out, X_[xc].p, n); break;
-        case 1: ensure_z(); copy_out(out, Z_[zc].p, n); break;
+        case 1: ensure_z(false); copy_out(out, Z_[zc].p, n); break;
         case 2: ensure_z(); copy_out(out, RES_[rc].p, n); break;
         case 3:
             if (!gx_valid) { algrad(X_[xc].p, GX_.p, SL_AUX); gx_valid = true; }
@@ -530,7 +530,7 @@ template <class T> class Solver final : public SolverBase {
             begin_dev(po2, x);                                       // alps.jl:66
             run_to_completion();
             const int64_t sub_it = k_;
-            ensure_z();
+            ensure_z(false);
             x = Z_[zc].p;                                            // x .= sub_sol
             objx = fraw_last + g_z;                                  // alps.jl:68
             tot_inner += sub_it;
@@ -631,7 +631,7 @@ template <class T> class Solver final : public SolverBase {
             begin_dev(po2, xs);                                      // sub_solver(f=fSlack, g=gSlack, x0=xSlack)
             run_to_completion();
             const int64_t sub_it = k_;
-            ensure_z();                                              // (the one-pass kernel keeps z in registers until it is asked for)
+            ensure_z(false);                                         // (the one-pass kernel keeps z in registers until it is asked for)
             xs = Z_[zc].p;                                           // xSlack .= sub_sol
             objx = fraw_last + g_z;                                  // f(x) + gSlack.gz       als.jl:79
             tot_inner += sub_it;
@@ -1450,8 +1450,10 @@ template <class T> class Solver final : public SolverBase {
     //   z = prox_{gamma g}(x - gamma grad L(x))   — the arithmetic of k_algrad_elem + k_fbstep, which the fused
     //   passes reproduce bit for bit (test_fused_equals_generic_bitwise)
     // (likewise the residual res = x - z into RES_[rc] when the pass did not store it)
-    void ensure_z() {
-        if (z_valid && res_valid) return;
+    // need_res = false: the caller reads z only (the solution of a subproblem, alps.jl:67): a z that the last pass stored is
+    // enough, whatever the state of res (the iterate-history passes never write it)
+    void ensure_z(bool need_res = true) {
+        if (z_valid && (res_valid || !need_res)) return;
         const int fb_env = fused_begin_env_;
         if (fb_env && desc.c_kind == BZ_C_IDENTITY && !slack && !dense_f && !lp_g &&
             (desc.f_kind == BZ_F_ZERO || desc.f_kind == BZ_F_DIAG_QUADRATIC)) {

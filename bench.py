@@ -466,9 +466,9 @@ def event_period(steps, short_pass=False):
         return int(os.environ["BZ_BENCH_PERIOD"])
     p = int(max(4, min(32, steps // 12)))
     if steps < 48:
-        # a short block (the driver's K = 20): two evented launches per block — five of them were 2 % of the block's time; the
+        # a short block (the driver's K = 20): ONE evented launch per block — five of them were 2 % of the block's time; the
         # roofline average then also takes the samples of the repeat blocks (same workload, same K: `roofline.sampled_blocks`)
-        p = int(max(4, steps // 2))
+        p = int(max(4, steps))      # (the block's first launch: it follows the warm-up's last single step, so it is a plain launch anyway)
     # a short pass (an N = 8 shard: ~20 us) feels the ~14 us an evented, un-gated launch costs twice as much: half as often
     return min(32, 2 * p) if short_pass else p
 

@@ -822,6 +822,7 @@ template <class T> class Solver final : public SolverBase {
     int xr_env_ = 2, skipz_env_ = 1;     // BZ_XR / BZ_SKIPZ, read at every bz_panoc_begin (tests toggle them)
     int gfc_env_ = 0, trialfuse_env_ = 1, fused_begin_env_ = 1;      // BZ_GFC / BZ_TRIALFUSE / BZ_FUSED_BEGIN, likewise
     int slackfast_env_ = 1;      // BZ_SLACKFAST=0: the slack iterate-history pass always in its run-time-kinds instantiation
+    int suc_grid_env_ = 1;       // BZ_SUC_GRID=k: k_stencil_update_c on k workgroups per CU (default 1; 0: the problem's grid)
     int stencil_regx_env_ = 1;   // BZ_STENCIL_REGX=0|1|2: cfg 3's second pass reads res and grad L(x_d) / re-forms res (default) / re-forms both (slower)
     int affblend_env_ = 1;       // BZ_AFFINE_BLEND=0: a tau-backtracked point of cfg 4 is always evaluated with a pass over A (no images)
     int densesmall_env_ = 1;     // BZ_DENSESMALL=0: cfg 4's short kernels either side of the pass over A as launches of their own (k_dense_head / k_dense_tail off)
@@ -2252,6 +2253,7 @@ template <class T> class Solver final : public SolverBase {
         densesmall_env_ = std::getenv("BZ_DENSESMALL") ? std::atoi(std::getenv("BZ_DENSESMALL")) : 1;
         affblend_env_ = std::getenv("BZ_AFFINE_BLEND") ? std::atoi(std::getenv("BZ_AFFINE_BLEND")) : 1;
         stencil_regx_env_ = std::getenv("BZ_STENCIL_REGX") ? std::atoi(std::getenv("BZ_STENCIL_REGX")) : 1;
+        suc_grid_env_ = std::getenv("BZ_SUC_GRID") ? std::atoi(std::getenv("BZ_SUC_GRID")) : 1;
         slackdepth_env_ = std::getenv("BZ_SLACKDEPTH") ? std::atoi(std::getenv("BZ_SLACKDEPTH")) : 1;
         // BZ_GATE: 0 off; 1 (default) the early launch queues behind the read-back on the solver's own stream; 2 on the other
         // stream (resident while the previous pass runs: measured slower, kept for the record)
@@ -2778,10 +2780,14 @@ template <class T> class Solver final : public SolverBase {
                 const StencilHalo<T> halo_z = halo_exchange(Z_[zn].p);
                 if (use_compact) {
                     // ... with the Gram products of the new pair and the next application's p, w in the same pass
-                    for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = grid;
+                    // (r03: this pass — 19 streams, 27 accumulators — runs best with ONE workgroup per CU, one resident round and a
+                    // 27-slot epilogue per CU: 102 us against 108 with two or four and 114 on the problem's grid of 2048, at 2048^2 ;
+                    // the other two passes want the largest grid.  BZ_SUC_GRID=k: k per CU, 0: `grid`.)
+                    const int g_upd = suc_grid_env_ > 0 ? std::min(grid, suc_grid_env_ * std::max(1, num_cus)) : grid;
+                    for (int sidx = 0; sidx < NFC; ++sidx) slot_n[SL_TRIAL + sidx] = sidx < 5 ? grid : g_upd;      // (slots 0..4: k_stencil_fb's)
                     mv(2 + pstreams(false, true, false) + (5 - regx) + 2 + 2 * CV.m);
 #define BZ_LAUNCH_SUC_R(FULL_, NT_, REGX_)                                                                        \
-    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_, REGX_>, grid, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
+    launch(C_STENCIL_UPD, k_stencil_update_c<T, CM, FULL_, NT_, REGX_>, g_upd, CV, (const T*)Z_[zn].p, P, (int64_t)desc.f_grid_nx, \
            (int64_t)desc.f_grid_ny, (const T*)X_[xd].p, (const T*)X_[xp].p, (const T*)RES_[rn].p, (const T*)RES_[rp].p, \
            (const T*)GX_.p, gamma, S_[spare].p, Y_[spare].p, n, parts_.p, (int)SL_TRIAL, halo_z, halo_x)
 #define BZ_LAUNCH_SUC(FULL_, NT_)                                                                                 \
